@@ -1,0 +1,138 @@
+"""Generate the golden vectors in this directory from the REAL reference.
+
+Run ONLY in the build container (needs /root/reference, which never travels):
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference ships no tests or fixtures of its own, so the
+files written here are the only pin for the oracle and, through it, for the HIP
+path.  Only inputs' seeds and the reference's OUTPUTS are stored (fp32 .npz);
+weights are regenerated on both sides from ``oracle.basicvsr_oracle.keyed_tensor``
+(a pure function of the state_dict key), so nothing of the reference's source or
+parameters is committed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+REF_SRC = "/root/reference/src"
+
+
+def import_reference():
+    """`vsrlab` -> /root/reference/src (the reference's setup.py:6-7 alias) plus a stub
+    for the unused ``torchvision.ops`` import at core/modules/conv.py:4."""
+    pkg = types.ModuleType("vsrlab")
+    pkg.__path__ = [REF_SRC]
+    sys.modules["vsrlab"] = pkg
+    tv = types.ModuleType("torchvision")
+    ops = types.ModuleType("torchvision.ops")
+
+    class DeformConv2d(nn.Module):
+        pass
+
+    ops.DeformConv2d = DeformConv2d
+    ops.deform_conv2d = None
+    tv.ops = ops
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = ops
+    from vsrlab.vsr.models.RealBasicVSR.modules import basicvsr, spynet
+    from vsrlab.vsr.models.RealBasicVSR import realbasicvsr
+    from vsrlab.core.modules import conv, upsampling
+    return basicvsr, spynet, realbasicvsr, conv, upsampling
+
+
+def load_keyed(module):
+    from oracle.basicvsr_oracle import keyed_tensor
+    sd = {k: keyed_tensor(k, tuple(v.shape)) for k, v in module.state_dict().items()}
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def rand(seed, *shape, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().numpy().astype(np.float32) if isinstance(v, torch.Tensor) else np.asarray(v))
+           for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    basicvsr, spynet, realbasicvsr, conv, upsampling = import_reference()
+
+    # ---- (i) per-op -------------------------------------------------------------
+    x = rand(1, 2, 5, 9, 11, lo=-1, hi=1)
+    flow = rand(2, 2, 2, 9, 11, lo=-8, hi=8)       # +-8 px incl. out-of-range taps
+    fl = flow.permute(0, 2, 3, 1)
+    save("flow_warp", seed_x=1, seed_flow=2,
+         zeros=spynet.flow_warp(x, fl), border=spynet.flow_warp(x, fl, padding_mode="border"))
+
+    rc = load_keyed(conv.ResidualConv(16))
+    xi = rand(3, 2, 16, 12, 20, lo=-1, hi=1)
+    save("residual_conv", seed_x=3, y=rc(xi))
+
+    rb = load_keyed(conv.ResidualBlock(19, 16, 2))
+    xi = rand(4, 2, 19, 12, 20, lo=-1, hi=1)
+    save("residual_block", seed_x=4, y=rb(xi))
+
+    ps = load_keyed(upsampling.PixelShufflePack(16, 16, 2))
+    xi = rand(5, 2, 16, 7, 9, lo=-1, hi=1)
+    save("pixel_shuffle_pack", seed_x=5, y=ps(xi))
+
+    # ---- (ii) SPyNet: 40x72 exercises the resize-to-/32 path; 32x32 the 1x1 level --
+    sp = load_keyed(spynet.Spynet(False))
+    a = rand(6, 2, 3, 40, 72)
+    b = rand(7, 2, 3, 40, 72)
+    a2 = rand(8, 1, 3, 32, 32)
+    b2 = rand(9, 1, 3, 32, 32)
+    with torch.no_grad():
+        save("spynet", seed_ref=6, seed_supp=7, flow=sp(a, b), seed_ref2=8, seed_supp2=9, flow2=sp(a2, b2))
+
+    # ---- (iii) end to end: sr, Charbonnier loss, selected grads --------------------
+    from oracle.basicvsr_oracle import charbonnier as _unused  # noqa: F401  (formula restated in-line below)
+    for tag, mid, blocks, shape in (("basicvsr_m16_rb2", 16, 2, (1, 3, 3, 32, 32)),
+                                    ("basicvsr_m64_rb3", 64, 3, (2, 3, 3, 24, 40))):
+        m = load_keyed(basicvsr.BasicVSR(mid, blocks, 4, False, False))
+        lrs = rand(10, *shape)
+        n, t, _, h, w = shape
+        hr = rand(11, n, t, 3, 4 * h, 4 * w)
+        sr = m(lrs)
+        d = sr - hr
+        loss = torch.mean(torch.sqrt(d * d + 1e-9))     # core/losses.py:15-17
+        # Gradients are pinned through a LINEAR functional mean(sr*cot): Charbonnier's own
+        # gradient d/sqrt(d^2+1e-9) flips sign on |d|~1e-5 and is ill-conditioned for parity.
+        cot = rand(13, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
+        torch.mean(sr * cot).backward()
+        named = dict(m.named_parameters())
+        keys = ["backward_resblocks.conv.0.weight", "backward_resblocks.conv.0.bias",
+                f"forward_resblocks.res_block.{blocks - 1}.conv2.weight",
+                "forward_resblocks.res_block.0.conv1.weight", "backward_resblocks.res_block.0.conv1.bias",
+                "point_conv.0.weight", "upsample.0.upconv.weight", "upsample.1.upconv.bias",
+                "conv_last.0.weight", "conv_last.2.weight", "conv_last.2.bias"]
+        grads = {"grad__" + k.replace(".", "__"): named[k].grad for k in keys}
+        with torch.no_grad():
+            ff, fb = m.compute_flow(lrs)
+        save(tag, seed_lr=10, seed_hr=11, seed_cot=13, sr=sr, loss=loss, flow_forward=ff, flow_backward=fb, **grads)
+
+    # ---- RealBasicVSR forward (cleaner); reference mutates its input, so pass a clone ----
+    m = load_keyed(realbasicvsr.RealBasicVSR(2, mid_channels=16, upscale=4, res_blocks=2,
+                                             pretrained_flow=False, train_flow=False))
+    lrs = rand(12, 1, 3, 3, 32, 32)
+    with torch.no_grad():
+        sr, lq = m(lrs.clone())
+    save("realbasicvsr_m16", seed_lr=12, sr=sr, lq=lq)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+"""Shared helpers for the test-suite (seeded inputs identical to tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rand(seed, *shape, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(int(seed))
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b|  -- the 'relative fp32' measure used by every parity test."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

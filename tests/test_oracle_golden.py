@@ -1,0 +1,102 @@
+"""CPU: the oracle restatement vs. golden vectors produced by the real reference
+(tests/golden/make_golden.py).  Tolerance: 1e-5 relative (both sides are fp32 ATen on CPU;
+the only differences are summation order inside the restated flow_warp)."""
+import pytest
+import torch
+
+from oracle import basicvsr_oracle as O
+from helpers import golden, rand, rel_err
+
+TOL = 1e-5
+
+
+def test_flow_warp_zeros_and_border():
+    g = golden("flow_warp")
+    x = rand(g["seed_x"], 2, 5, 9, 11, lo=-1, hi=1)
+    flow = rand(g["seed_flow"], 2, 2, 9, 11, lo=-8, hi=8)
+    assert rel_err(O.flow_warp(x, flow, "zeros"), g["zeros"]) < TOL
+    assert rel_err(O.flow_warp(x, flow, "border"), g["border"]) < TOL
+
+
+def test_residual_conv():
+    g = golden("residual_conv")
+    sd = O.keyed_state_dict({f"conv{j}.{p}": s for j in (1, 2)
+                             for p, s in (("weight", (16, 16, 3, 3)), ("bias", (16,)))})
+    x = rand(g["seed_x"], 2, 16, 12, 20, lo=-1, hi=1)
+    assert rel_err(O.residual_conv(sd, "", x), g["y"]) < TOL
+
+
+def test_residual_block():
+    g = golden("residual_block")
+    shapes = {"conv.0.weight": (16, 19, 3, 3), "conv.0.bias": (16,)}
+    for i in range(2):
+        for j in (1, 2):
+            shapes[f"res_block.{i}.conv{j}.weight"] = (16, 16, 3, 3)
+            shapes[f"res_block.{i}.conv{j}.bias"] = (16,)
+    sd = O.keyed_state_dict(shapes)
+    x = rand(g["seed_x"], 2, 19, 12, 20, lo=-1, hi=1)
+    assert rel_err(O.residual_block(sd, "", x, 2), g["y"]) < TOL
+
+
+def test_pixel_shuffle_pack():
+    g = golden("pixel_shuffle_pack")
+    sd = O.keyed_state_dict({"upconv.weight": (64, 16, 3, 3), "upconv.bias": (64,)})
+    x = rand(g["seed_x"], 2, 16, 7, 9, lo=-1, hi=1)
+    assert rel_err(O.pixel_shuffle_pack(sd, "", x), g["y"]) < TOL
+
+
+def test_spynet_resize_path_and_1x1_level():
+    g = golden("spynet")
+    sd = O.keyed_state_dict(O.spynet_param_shapes())
+    a = rand(g["seed_ref"], 2, 3, 40, 72)
+    b = rand(g["seed_supp"], 2, 3, 40, 72)
+    with torch.no_grad():
+        assert rel_err(O.spynet_forward(sd, a, b), g["flow"]) < TOL
+        a2 = rand(g["seed_ref2"], 1, 3, 32, 32)
+        b2 = rand(g["seed_supp2"], 1, 3, 32, 32)
+        assert rel_err(O.spynet_forward(sd, a2, b2), g["flow2"]) < TOL
+
+
+@pytest.mark.parametrize("tag,mid,blocks,shape", [("basicvsr_m16_rb2", 16, 2, (1, 3, 3, 32, 32)),
+                                                  ("basicvsr_m64_rb3", 64, 3, (2, 3, 3, 24, 40))])
+def test_basicvsr_end_to_end_fwd_bwd(tag, mid, blocks, shape):
+    g = golden(tag)
+    sd = O.keyed_state_dict(O.basicvsr_param_shapes(mid, blocks, 4))
+    n, t, _, h, w = shape
+    lrs = rand(g["seed_lr"], *shape)
+    hr = rand(g["seed_hr"], n, t, 3, 4 * h, 4 * w)
+    with torch.no_grad():
+        ff, fb = O.basicvsr_compute_flow(sd, lrs)
+    assert rel_err(ff.reshape(-1, 2, h, w), g["flow_forward"]) < TOL
+    assert rel_err(fb.reshape(-1, 2, h, w), g["flow_backward"]) < TOL
+    cot = rand(g["seed_cot"], n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
+    sr, loss, grads = O.fwd_bwd(sd, lrs, hr, cot=cot)
+    assert rel_err(sr, g["sr"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"])) + 1e-7
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            name = k[len("grad__"):].replace("__", ".")
+            assert rel_err(grads[name], v) < 5e-4, name  # fp32 reduction-order noise on the deepest (cancelling) grads is ~2e-4
+            checked += 1
+    assert checked == 11
+    assert not any("spynet" in k for k in grads)       # frozen flow net: basicvsr.py:25-28
+
+
+def test_realbasicvsr_forward():
+    g = golden("realbasicvsr_m16")
+    shapes = {"basicvsr." + k: s for k, s in O.basicvsr_param_shapes(16, 2, 4).items()}
+    shapes["cleaner.resblock.conv.0.weight"] = (16, 3, 3, 3)
+    shapes["cleaner.resblock.conv.0.bias"] = (16,)
+    for i in range(2):
+        for j in (1, 2):
+            shapes[f"cleaner.resblock.res_block.{i}.conv{j}.weight"] = (16, 16, 3, 3)
+            shapes[f"cleaner.resblock.res_block.{i}.conv{j}.bias"] = (16,)
+    shapes["cleaner.conv.weight"] = (3, 16, 3, 3)
+    shapes["cleaner.conv.bias"] = (3,)
+    sd = O.keyed_state_dict(shapes)
+    lrs = rand(g["seed_lr"], 1, 3, 3, 32, 32)
+    with torch.no_grad():
+        sr, lq = O.realbasicvsr_forward(sd, lrs)
+    assert rel_err(lq, g["lq"]) < TOL
+    assert rel_err(sr, g["sr"]) < TOL
