@@ -1,0 +1,125 @@
+/* vsrlab_hip.h -- C ABI of libvsrlab_hip.so: the MI355X-native BasicVSR forward/backward path.
+ *
+ * The reference (santurini/vsrlab) has no FFI: its boundary for this path is the Python
+ * nn.Module protocol `sr = BasicVSR(...)(lrs)` resolved by Hydra `_target_`
+ * (src/core/utils.py:138; src/vsr/models/RealBasicVSR/modules/basicvsr.py:39-83).  This header is
+ * what a binding for that path attaches to: plain pointers and sizes, no torch types.  Every entry
+ * point
+ *   - takes DEVICE pointers (HBM) unless stated otherwise, and a hipStream_t passed as void*;
+ *   - only enqueues work on that stream: no allocation, no synchronisation, no global mutable
+ *     state -- it may be called from PyTorch's main thread and from its autograd thread;
+ *   - returns 0 (VSR_OK) or a negative status, never throws.
+ *
+ * Tensor conventions
+ *   boundary tensors are the reference's own: LR clip (n,t,3,h,w) fp32 planar, SR clip
+ *   (n,t,3,4h,4w) fp32 planar, parameters/gradients fp32 OIHW, flow (N,2,H,W) fp32 planar with
+ *   channel 0 = dx.  "pm" (pixel-major) tensors are the library's internal [N][H][W][C] layout with
+ *   element type `dtype` (VSR_DT_F32 / VSR_DT_BF16); per-op entry points that take them exist so
+ *   that each kernel can be parity-tested in isolation.
+ */
+#ifndef VSRLAB_HIP_H
+#define VSRLAB_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSR_DT_F32 0   /* exact-fp32 build: v_mfma_f32_32x32x2_f32, parity gate */
+#define VSR_DT_BF16 1  /* bf16 storage, fp32 accumulate: v_mfma_f32_32x32x16_bf16, perf build */
+
+#define VSR_STATUS_OK 0
+#define VSR_STATUS_BADARG (-1)
+#define VSR_STATUS_UNSUPPORTED (-2)
+#define VSR_STATUS_HIP (-3)
+#define VSR_STATUS_WORKSPACE (-4)
+
+int vsr_abi_version(void);
+const char* vsr_status_string(int status);
+
+/* ---- whole-path engine -------------------------------------------------------------------
+ * Replaces BasicVSR.forward and its autograd backward (basicvsr.py:39-83).
+ * mid_channels must be 64 and upscale 4 (the reference's defaults, basicvsr.py:12-13);
+ * res_blocks >= 1; t <= 32 (test.py's window).                                              */
+typedef struct VsrBasicVSRDesc {
+    int n, t, h, w;      /* LR clip (n,t,3,h,w) */
+    int mid_channels;
+    int res_blocks;
+    int upscale;
+    int dtype;           /* VSR_DT_* of the internal activations */
+} VsrBasicVSRDesc;
+
+/* Number of parameter tensors.  Order, by the reference module's state_dict KEYS (state_dict()
+ * itself lists spynet.mean/std before the SPyNet convs; this ABI puts them last):
+ *   for trunk in (backward_resblocks, forward_resblocks):
+ *       conv.0.weight, conv.0.bias, then res_block.{i}.conv1.{weight,bias}, conv2.{weight,bias}
+ *   point_conv.0.{weight,bias}; upsample.{0,1}.upconv.{weight,bias};
+ *   conv_last.0.{weight,bias}; conv_last.2.{weight,bias};
+ *   spynet.basic_module.{0..5}.basic_module.{0..4}.conv.0.{weight,bias}; spynet.mean; spynet.std */
+int vsr_basicvsr_num_params(const VsrBasicVSRDesc* d);
+
+/* Bytes of workspace the caller must provide (same buffer for forward and its backward).
+ * need_backward = 0: inference (activations are not retained).                              */
+size_t vsr_basicvsr_workspace_bytes(const VsrBasicVSRDesc* d, int need_backward);
+
+/* sr = BasicVSR(lrs).  `params`: HOST array of num_params device pointers.                   */
+int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, int nparams,
+                         const float* lrs, float* sr, void* workspace, size_t workspace_bytes,
+                         int need_backward, void* stream);
+
+/* Back-propagates dsr (n,t,3,4h,4w) through the forward that last ran on `workspace`
+ * (need_backward=1).  grads[k] (same order/shape as params; NULL = not wanted; SPyNet entries
+ * are ignored: train_flow=False, basicvsr.py:25-28) are ACCUMULATED into (+=).                */
+int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads,
+                          int nparams, const float* lrs, const float* dsr, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* Copies the optical flows computed by the last forward: (n,t-1,2,h,w) each
+ * (BasicVSR.compute_flow, basicvsr.py:30-37).                                               */
+int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, float* flow_forward,
+                           float* flow_backward, void* stream);
+
+/* ---- SPyNet alone: flow = Spynet(ref, supp)  (RealBasicVSR/modules/spynet.py:69-93) -------
+ * ref/supp (N,3,h,w) fp32 planar; params: the 62 spynet tensors in state_dict order.        */
+size_t vsr_spynet_workspace_bytes(int N, int h, int w, int dtype);
+int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* params, int nparams,
+                       const float* ref, const float* supp, float* flow, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ---- per-op entry points (pixel-major tensors) --------------------------------------------- */
+/* flow_warp, zeros padding (spynet.py:95-106): out[n,y,x,:] = bilinear(in[n], x+fx, y+fy)     */
+int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H,
+                      int W, int C, void* stream);
+/* its backward w.r.t. `in`: dacc (fp32 pixel-major, caller-zeroed) += scatter(dout)           */
+int vsr_flow_warp_bwd(int dtype, const void* dout_pm, const float* flow, float* dacc_pm_f32, int N,
+                      int H, int W, int C, void* stream);
+
+/* layout converters between the reference's planar fp32 and pixel-major `dtype`              */
+int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int C,
+                     void* stream);
+int vsr_pm_to_planar(int dtype, const void* in_pm, float* out, int N, int Cout, int H, int W, int C,
+                     void* stream);
+
+/* y = act(conv3x3(x, w) + b) [+ res]   64->64, stride 1, pad 1 (core/modules/conv.py:85-86).
+ * w: fp32 OIHW (64,64,3,3) ; wpack: scratch of 9*64*64 elements of `dtype`;
+ * act: 0 none / 1 ReLU / 2 LeakyReLU(0.1); res_pm may be NULL.                               */
+int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float* b, void* wpack,
+                        void* y_pm, const void* res_pm, int act, int N, int H, int W, void* stream);
+/* dx = conv3x3_transpose(dy, w) (+res) (* mask(aux)): the data gradient of the same conv;
+ * mask_mode: 0 none / 1 ReLU' of aux / 2 LeakyReLU' of aux                                   */
+int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm,
+                          const void* res_pm, const void* aux_pm, int mask_mode, int N, int H,
+                          int W, void* stream);
+/* gw (64,64,3,3) and gb (64) fp32, overwritten.  slab: fp32 scratch of
+ * vsr_conv3x3_c64_wgrad_slab_floats() floats.                                                */
+size_t vsr_conv3x3_c64_wgrad_slab_floats(void);
+int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float* gw, float* gb,
+                          float* slab, int N, int H, int W, void* stream);
+
+/* Charbonnier loss value and gradient (core/losses.py:10-18): loss = mean(sqrt((sr-hr)^2+eps)) */
+int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, long long numel,
+                            float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSRLAB_HIP_H */

@@ -1,0 +1,310 @@
+"""GPU parity tests: every call goes through the C ABI (libvsrlab_hip.so via vsrlab_amd) and is
+checked against the CPU oracle (oracle/basicvsr_oracle.py, itself pinned to the reference by
+tests/golden) and against the committed golden vectors.
+
+Tolerances
+  fp32 build : 1e-3 relative (max|a-b|/max|b|) -- the north-star bar; observed ~1e-5 forward.
+               Weight gradients are additionally bounded in relative L2 because ReLU/LeakyReLU
+               masks are discontinuous: two exact-fp32 implementations differ by up to ~2e-3 in
+               max-norm on a few elements (measured: reference fp32 vs reference fp64).
+  bf16 build : inputs/weights are rounded to bf16 and every stored activation is bf16 (8 bits of
+               mantissa), so: per-op 1e-2 relative to the oracle run on the SAME bf16-rounded
+               inputs; end-to-end 4e-2 (sr) / 8e-2 relative L2 (grads) vs the fp32 oracle.
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, rand, rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+from oracle import basicvsr_oracle as O  # noqa: E402  (checker only)
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests need an MI355X")
+    return torch.device("cuda:0")
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def tol(dtype, fp32, bf16):
+    return fp32 if dtype == "fp32" else bf16
+
+
+DTYPES = ["fp32", "bf16"]
+
+
+# --------------------------------------------------------------------------------------------- #
+def test_library_loaded_and_abi():
+    import vsrlab_amd
+    lib = vsrlab_amd._lib.load()
+    assert lib.vsr_abi_version() == 1
+    _gpu()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_roundtrip(dtype):
+    from vsrlab_amd import functional as VF
+    dev = _gpu()
+    x = rand(21, 2, 5, 9, 11, lo=-1, hi=1)
+    pm = VF.to_pixel_major(x.to(dev), VF.resolve_dtype(dtype))
+    assert pm.shape == (2, 9, 11, 16)
+    back = VF.from_pixel_major(pm, 5).cpu()
+    ref = x if dtype == "fp32" else bf16_round(x)
+    assert torch.equal(back, ref)
+    assert float(VF.from_pixel_major(pm).cpu()[:, 5:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_flow_warp_forward_backward_vs_oracle_and_golden(dtype):
+    from vsrlab_amd import functional as VF
+    dev = _gpu()
+    g = golden("flow_warp")
+    x = rand(g["seed_x"], 2, 5, 9, 11, lo=-1, hi=1)
+    flow = rand(g["seed_flow"], 2, 2, 9, 11, lo=-8, hi=8)
+    xin = x if dtype == "fp32" else bf16_round(x)
+    xg = xin.clone().to(dev).requires_grad_(True)
+    out = VF.flow_warp(xg, flow.permute(0, 2, 3, 1).to(dev), compute_dtype=dtype)
+    cot = rand(22, 2, 5, 9, 11, lo=-1, hi=1)
+    cot_in = cot if dtype == "fp32" else bf16_round(cot)
+    out.backward(cot_in.to(dev))
+    xo = xin.clone().requires_grad_(True)
+    ref = O.flow_warp(xo, flow, "zeros")
+    ref.backward(cot_in)
+    assert rel_err(out, ref) < tol(dtype, 1e-5, 1e-2)
+    assert rel_err(xg.grad, xo.grad) < tol(dtype, 1e-5, 1e-5)      # scatter accumulates in fp32 in both builds
+    if dtype == "fp32":
+        assert rel_err(out, g["zeros"]) < 1e-5                      # the reference's own output
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 8, 32), (2, 13, 37), (1, 40, 72)])
+def test_conv3x3_c64_fwd_dgrad_wgrad(dtype, shape):
+    """The trunk's hot kernel family (conv.py:85-86) incl. ragged tiles (H,W not multiples of 8,32)."""
+    from vsrlab_amd import functional as VF
+    dev = _gpu()
+    n, h, w = shape
+    dt = VF.resolve_dtype(dtype)
+    rnd = (lambda t: t) if dtype == "fp32" else bf16_round
+    x = rnd(rand(31, n, 64, h, w, lo=-1, hi=1))
+    wgt = rnd(O.keyed_tensor("test.conv.weight", (64, 64, 3, 3)))
+    b = O.keyed_tensor("test.conv.bias", (64,))
+    res = rnd(rand(32, n, 64, h, w, lo=-1, hi=1))
+    dy = rnd(rand(33, n, 64, h, w, lo=-1, hi=1))
+    xp, rp, dyp = (VF.to_pixel_major(t.to(dev), dt) for t in (x, res, dy))
+    t_out = tol(dtype, 2e-5, 1e-2)
+    # forward: relu(conv + b) + res
+    y = VF.from_pixel_major(VF.conv3x3_c64(xp, wgt.to(dev), b.to(dev), act=1, res_pm=rp)).cpu()
+    ref = F.relu(F.conv2d(x, wgt, b, padding=1)) + res
+    assert rel_err(y, ref) < t_out
+    # leaky variant, no residual
+    y = VF.from_pixel_major(VF.conv3x3_c64(xp, wgt.to(dev), b.to(dev), act=2)).cpu()
+    assert rel_err(y, F.leaky_relu(F.conv2d(x, wgt, b, padding=1), 0.1)) < t_out
+    # data gradient with ReLU mask and with residual
+    dref = F.conv_transpose2d(dy, wgt, padding=1)
+    dx = VF.from_pixel_major(VF.conv3x3_c64_dgrad(dyp, wgt.to(dev), aux_pm=rp, mask_mode=1)).cpu()
+    assert rel_err(dx, dref * (res > 0)) < t_out
+    dx = VF.from_pixel_major(VF.conv3x3_c64_dgrad(dyp, wgt.to(dev), res_pm=rp, aux_pm=xp, mask_mode=2)).cpu()
+    assert rel_err(dx, (dref + res) * torch.where(x > 0, 1.0, 0.1)) < t_out
+    # weight / bias gradient (fp32 accumulation, fp32 output in both builds)
+    gw, gb = VF.conv3x3_c64_wgrad(xp, dyp)
+    xr = x.clone().requires_grad_(False)
+    wr = wgt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    (F.conv2d(xr, wr, br, padding=1) * dy).sum().backward()
+    assert rel_err(gw.cpu(), wr.grad) < 2e-5
+    assert rel_err(gb.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_residual_conv_module_fwd_bwd(dtype):
+    from vsrlab_amd.core.modules.conv import ResidualConv
+    dev = _gpu()
+    sd = O.keyed_state_dict({f"conv{j}.{p}": s for j in (1, 2) for p, s in (("weight", (64, 64, 3, 3)), ("bias", (64,)))})
+    m = ResidualConv(64)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    x = rand(41, 2, 64, 20, 36, lo=-1, hi=1)
+    cot = rand(42, 2, 64, 20, 36, lo=-1, hi=1)
+    import os
+    os.environ["VSRLAB_AMD_DTYPE"] = dtype
+    try:
+        xg = x.clone().to(dev).requires_grad_(True)
+        y = m(xg)
+        y.backward(cot.to(dev))
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]
+    leaves = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().double().requires_grad_(True)
+    yo = O.residual_conv(leaves, "", xo)
+    yo.backward(cot.double())
+    assert rel_err(y, yo) < tol(dtype, 1e-4, 2e-2)
+    assert rel_l2(xg.grad, xo.grad) < tol(dtype, 1e-3, 3e-2)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < tol(dtype, 1e-3, 3e-2), k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_spynet_vs_oracle_and_golden(dtype):
+    """40x72 exercises the resize-to-/32 path, 32x32 the 1x1 coarsest level."""
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.spynet import Spynet
+    dev = _gpu()
+    g = golden("spynet")
+    m = Spynet(False)
+    m.load_state_dict(O.keyed_state_dict(O.spynet_param_shapes()), strict=True)
+    m = m.to(dev).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    import os
+    os.environ["VSRLAB_AMD_DTYPE"] = dtype
+    try:
+        f1 = m(rand(g["seed_ref"], 2, 3, 40, 72).to(dev), rand(g["seed_supp"], 2, 3, 40, 72).to(dev)).cpu()
+        f2 = m(rand(g["seed_ref2"], 1, 3, 32, 32).to(dev), rand(g["seed_supp2"], 1, 3, 32, 32).to(dev)).cpu()
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]
+    # flows reach ~13 px; bf16: six levels of 5 bf16 convs feeding a x2-per-level recursion
+    assert rel_err(f1, g["flow"]) < tol(dtype, 1e-3, 5e-2)
+    assert rel_err(f2, g["flow2"]) < tol(dtype, 1e-3, 5e-2)
+
+
+def _run_basicvsr(dtype, mid, blocks, shape, seed_lr, seed_cot, dev, charbonnier_hr=None):
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    m = BasicVSR(mid, blocks, 4, False, False)
+    m.load_state_dict(O.keyed_state_dict(O.basicvsr_param_shapes(mid, blocks, 4)), strict=True)
+    m = m.to(dev)
+    m.compute_dtype = dtype
+    n, t, _, h, w = shape
+    lrs = rand(seed_lr, *shape)
+    cot = rand(seed_cot, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
+    sr = m(lrs.to(dev))
+    torch.mean(sr * cot.to(dev)).backward()
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    return m, lrs, cot, sr.detach().cpu(), grads
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_basicvsr_end_to_end_vs_golden(dtype):
+    """(2,3,3,24,40), mid 64, 3 blocks: sr + 11 parameter gradients against the reference's own
+    (fp64) outputs, and the flows against the reference's compute_flow."""
+    dev = _gpu()
+    g = golden("basicvsr_m64_rb3")
+    shape = (2, 3, 3, 24, 40)
+    m, lrs, cot, sr, grads = _run_basicvsr(dtype, 64, 3, shape, int(g["seed_lr"]), int(g["seed_cot"]), dev)
+    assert rel_err(sr, g["sr"]) < tol(dtype, 1e-3, 4e-2)
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            name = k[len("grad__"):].replace("__", ".")
+            assert rel_l2(grads[name], v) < tol(dtype, 1e-3, 8e-2), name
+            assert rel_err(grads[name], v) < tol(dtype, 5e-3, 2e-1), name
+            checked += 1
+    assert checked == 11
+    assert not any(k.startswith("spynet") for k in grads)
+    # flows computed inside the engine
+    from vsrlab_amd import functional as VF
+    ws = next(iter(m._pool._pool.values()))[0]
+    ff, fb = VF.basicvsr_flows(shape, 64, 3, 4, ws, VF.resolve_dtype(dtype), dev)
+    assert rel_err(ff.reshape(-1, 2, 24, 40).cpu(), g["flow_forward"]) < tol(dtype, 1e-3, 5e-2)
+    assert rel_err(fb.reshape(-1, 2, 24, 40).cpu(), g["flow_backward"]) < tol(dtype, 1e-3, 5e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_basicvsr_config1_all_grads_vs_oracle(dtype):
+    """BASELINE config 1: n=2, t=5, 64x64 LR, BasicVSR(64, 30): sr, Charbonnier loss and EVERY
+    trainable gradient against the fp64 oracle."""
+    dev = _gpu()
+    shape = (2, 5, 3, 64, 64)
+    m, lrs, cot, sr, grads = _run_basicvsr(dtype, 64, 30, shape, 10, 13, dev)
+    sd = {k: v.double() for k, v in O.keyed_state_dict(O.basicvsr_param_shapes(64, 30, 4)).items()}
+    hr = rand(11, 2, 5, 3, 256, 256).double()
+    sr_o, loss_o, grads_o = O.fwd_bwd(sd, lrs.double(), hr, cot=cot.double())
+    assert rel_err(sr, sr_o) < tol(dtype, 1e-3, 4e-2)
+    from vsrlab_amd.core.losses import CharbonnierLoss
+    loss = CharbonnierLoss()(sr.to(dev), hr.float().to(dev))
+    assert abs(float(loss) - float(loss_o)) < tol(dtype, 1e-4, 2e-2) * float(loss_o)
+    assert set(grads) == set(grads_o)
+    worst = max((rel_l2(grads[k], grads_o[k]), k) for k in grads_o)
+    assert worst[0] < tol(dtype, 1e-3, 8e-2), worst
+
+
+def test_ragged_sizes_and_single_frame():
+    """h,w not multiples of the 8x32 tile nor of 32 (SPyNet resize path); t=1 (no flow at all);
+    batch consistency: two identical clips in a batch give identical outputs."""
+    dev = _gpu()
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    sd32 = O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4))
+    m = BasicVSR(64, 2, 4, False, False)
+    m.load_state_dict(sd32, strict=True)
+    m = m.to(dev)
+    m.compute_dtype = "fp32"
+    for shape in [(1, 3, 3, 21, 45), (1, 1, 3, 16, 16), (1, 2, 3, 9, 70)]:
+        lrs = rand(51, *shape)
+        with torch.no_grad():
+            sr = m(lrs.to(dev)).cpu()
+            ref = O.basicvsr_forward(sd32, lrs)
+        assert rel_err(sr, ref) < 1e-3, shape
+    lrs = rand(52, 1, 3, 3, 24, 40)
+    with torch.no_grad():
+        both = m(torch.cat([lrs, lrs], 0).to(dev)).cpu()
+        one = m(lrs.to(dev)).cpu()
+    assert torch.equal(both[0], both[1])
+    assert rel_err(both[0:1], one) < 1e-6
+
+
+def test_inference_matches_training_forward_and_no_cpu_fallback():
+    dev = _gpu()
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    m = BasicVSR(64, 2, 4, False, False)
+    m.load_state_dict(O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4)), strict=True)
+    lrs = rand(53, 1, 3, 3, 24, 40)
+    with pytest.raises(RuntimeError):
+        m(lrs)                                   # CPU tensors: fail loudly, never fall back
+    m = m.to(dev)
+    m.compute_dtype = "bf16"
+    sr_train = m(lrs.to(dev))
+    with torch.no_grad():
+        sr_inf = m(lrs.to(dev))
+    assert torch.equal(sr_train.detach().cpu(), sr_inf.cpu())   # in-place inference schedule == retained schedule
+
+
+def test_backward_is_linear_in_cotangent_large():
+    """Size-independent property at a large frame (540x960, t=2): backward(a*c1 + c2) ==
+    a*backward(c1) + backward(c2), through the C ABI on one retained forward (bf16 build)."""
+    dev = _gpu()
+    import vsrlab_amd
+    from vsrlab_amd import functional as VF
+    from vsrlab_amd._order import basicvsr_keys
+    lib = vsrlab_amd._lib.load()
+    n, t, h, w, rb = 1, 2, 540, 960, 2
+    sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, rb, 4))
+    keys, n_train = basicvsr_keys(rb)
+    ps = [sd[k].to(dev).contiguous() for k in keys]
+    desc = vsrlab_amd._lib.BasicVSRDesc(n, t, h, w, 64, rb, 4, VF.DT_BF16)
+    nbytes = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(desc), 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    lrs = torch.rand(n, t, 3, h, w, device=dev)
+    sr = torch.empty(n, t, 3, 4 * h, 4 * w, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.vsr_basicvsr_forward(ctypes.byref(desc), VF._ptr_array(ps), len(ps), VF._ptr(lrs), VF._ptr(sr), VF._ptr(ws), nbytes, 1, st) == 0
+    assert bool(torch.isfinite(sr).all())
+
+    def bwd(cot):
+        gs = [torch.zeros_like(p) if k < n_train else None for k, p in enumerate(ps)]
+        assert lib.vsr_basicvsr_backward(ctypes.byref(desc), VF._ptr_array(ps), VF._ptr_array(gs), len(ps), VF._ptr(lrs), VF._ptr(cot),
+                                         VF._ptr(ws), nbytes, st) == 0
+        return torch.cat([g.flatten() for g in gs if g is not None])
+
+    c1 = torch.randn_like(sr)
+    c2 = torch.randn_like(sr)
+    g1, g2, g12 = bwd(c1), bwd(c2), bwd(0.5 * c1 + c2)
+    assert bool(torch.isfinite(g12).all())
+    # every product dY*X is formed from bf16-rounded activation gradients: linear up to bf16 rounding
+    assert rel_l2(g12, 0.5 * g1 + g2) < 2e-2
+    assert rel_l2(bwd(c1), g1) < 1e-3          # atomics in the warp scatter: order noise only

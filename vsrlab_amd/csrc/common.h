@@ -1,0 +1,95 @@
+// Shared device/host declarations for the vsrlab_amd HIP library (gfx950 / CDNA4 only).
+//
+// Data layout in HBM
+//   * boundary tensors (what PyTorch sees): LR clip / SR clip / cotangents are planar
+//     fp32 NCHW, parameters and their gradients are fp32 OIHW -- exactly the reference's
+//     tensors (basicvsr.py:39-83).
+//   * everything internal to the path is "pixel-major": [N][H][W][C] with C a multiple of
+//     16, element type T = bf16 (perf build) or fp32 (parity build).  One 64-channel pixel
+//     in bf16 is exactly one 128-byte line, so tile rows are long contiguous bursts and an
+//     MFMA B-fragment (8 consecutive channels of one pixel) is one 16-byte LDS read.
+//   * optical flow is planar fp32 [N][2][H][W] (channel 0 = dx), coalesced along x.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VSR_OK 0
+#define VSR_ERR_BADARG (-1)
+#define VSR_ERR_UNSUPPORTED (-2)
+#define VSR_ERR_HIP (-3)
+#define VSR_ERR_WORKSPACE (-4)
+
+#define VSR_F32 0
+#define VSR_BF16 1
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define VSR_MAX_SRC 4
+#define VSR_MAX_Z 4
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+enum { MASK_NONE = 0, MASK_RELU = 1, MASK_LEAKY = 2 };
+enum { EPI_NHWC = 0, EPI_PLANAR = 1 };
+
+// One implicit-GEMM convolution launch (stride 1, "same" zero padding, KS x KS).
+// The input is the concatenation of up to 4 sources along the channel axis; each source is
+// a strided *view* of an underlying pixel-major image:  view(y,x) = img(y*in_step+oy, x*in_step+ox).
+// Up to 4 independent sub-convolutions (z) share the input and differ in weights/bias/output
+// placement -- that is how conv+PixelShuffle(2) (core/modules/upsampling.py:10-12) is one launch.
+struct ConvArgs {
+    const void* src[VSR_MAX_SRC];
+    long long src_nstride[VSR_MAX_SRC];  // elements between images of the batch
+    int src_oy[VSR_MAX_SRC], src_ox[VSR_MAX_SRC];
+    int in_step, Hs, Ws;                 // underlying source image (pixels)
+    int N, H, W;                         // batch and conv (= view = output-view) size
+    const void* wpack;                   // packed weights, see pack_weights_kernel
+    long long w_zstride;                 // elements between the weight sets of consecutive z
+    const float* bias;                   // [z][bias_zstride] fp32 or null
+    int bias_zstride;
+    int nz;
+    void* dst[VSR_MAX_Z];
+    long long dst_nstride;
+    int out_step, Hd, Wd;                // underlying destination image (pixels)
+    int out_oy[VSR_MAX_Z], out_ox[VSR_MAX_Z];
+    int CD;                              // channels per destination pixel (pixel-major dst)
+    int cout_real;                       // real output channels (<= COUT template)
+    int act;
+    const void* res[VSR_MAX_Z];          // optional residual, destination layout, type T
+    const void* aux[VSR_MAX_Z];          // optional activation-mask source, destination layout, type T
+    int mask_mode;
+    // EPI_PLANAR: fp32 planar destination [N][cout_real][Hd][Wd] (+ optional planar residual,
+    // + optional bilinear x4 of a planar LR frame: basicvsr.py:22,82)
+    const float* pres;
+    const float* base_lr;
+    long long base_nstride;
+    int base_h, base_w;
+};
+
+// Weight-gradient launch: dW[z][tap][cout][cin] = sum_p dY[p][cout] * X[p + tap][cin] over up to
+// VSR_WG_MAXSEG (X, dY) segment pairs (the frames of a clip share one launch and one reduction).
+#define VSR_WG_MAXSEG 8
+struct WgradArgs {
+    const void* x[VSR_WG_MAXSEG];
+    const void* dy[VSR_WG_MAXSEG];
+    long long x_nstride, dy_nstride;
+    int nseg;
+    int N, H, W;                 // view size (x view == dy view)
+    int x_step, x_oy, x_ox, Hx, Wx;   // x view -> underlying image
+    int dy_step, dy_oy, dy_ox, Hy, Wy; // dy view -> underlying image
+    float* slab;                 // [gridDim.x][slab_stride] fp32 partials
+    int slab_stride;
+    int ntiles_x, ntiles_y;
+};
+
+static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define HIP_CHECK_RET(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return VSR_ERR_HIP;             \
+    } while (0)

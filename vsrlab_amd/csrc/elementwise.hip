@@ -1,0 +1,395 @@
+// Bandwidth-bound kernels of the BasicVSR path: flow_warp (forward gather / backward scatter),
+// the SPyNet pyramid plumbing (resize, normalise, average-pool, per-level warp+concat, flow
+// upsample), weight packing and small glue.  All are pure streaming kernels: one pass, 16-byte
+// accesses on pixel-major tensors, planar fp32 accesses coalesced along x.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct EW;
+template <> struct EW<bf16_t> { typedef uint4 chunk_t; };
+struct echunk32_t { uint4 a, b; };
+template <> struct EW<float> { typedef echunk32_t chunk_t; };
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    union { uint4 u; bf16_t h[8]; } t; t.u = v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)t.h[j];
+}
+__device__ __forceinline__ void unpack8(const echunk32_t& v, float* f) {
+    f[0] = __uint_as_float(v.a.x); f[1] = __uint_as_float(v.a.y); f[2] = __uint_as_float(v.a.z); f[3] = __uint_as_float(v.a.w);
+    f[4] = __uint_as_float(v.b.x); f[5] = __uint_as_float(v.b.y); f[6] = __uint_as_float(v.b.z); f[7] = __uint_as_float(v.b.w);
+}
+__device__ __forceinline__ void pack8(const float* f, uint4& v) {
+    union { uint4 u; bf16_t h[8]; } t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.h[j] = (bf16_t)f[j];
+    v = t.u;
+}
+__device__ __forceinline__ void pack8(const float* f, echunk32_t& v) {
+    v.a = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    v.b = make_uint4(__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7]));
+}
+
+// Sample position of flow_warp (spynet.py:95-106).  The reference normalises the pixel grid to
+// [-1,1] and grid_sample(align_corners=True) maps it back; we reproduce that round trip so the
+// fp32 rounding of the coordinate matches the reference's.
+__device__ __forceinline__ float warp_coord(float base, float flow, int dim) {
+    const float d = (float)(dim - 1 > 1 ? dim - 1 : 1);
+    const float g = 2.0f * (base + flow) / d - 1.0f;
+    return (g + 1.0f) * 0.5f * (float)(dim - 1);
+}
+
+// out[n,y,x,:] = bilinear(in[n], (x+fx, y+fy)), zeros padding (each out-of-image tap contributes 0).
+template <typename T>
+__global__ void warp_fwd_kernel(const T* __restrict__ in, const float* __restrict__ flow, T* __restrict__ out,
+                                int N, int H, int W, int C, long long flow_nstride) {
+    typedef typename EW<T>::chunk_t chunk_t;
+    const int CP = C / 8;
+    const long long total = (long long)N * H * W * CP;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CP);
+        const long long pix = idx / CP;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
+        const float px = warp_coord((float)x, fp[0], W);
+        const float py = warp_coord((float)y, fp[(long long)H * W], H);
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        float accv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accv[j] = 0.f;
+        const T* img = in + (long long)n * H * W * C;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+            const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+            if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+                float f[8];
+                unpack8(*reinterpret_cast<const chunk_t*>(img + ((long long)yi * W + xi) * C + c * 8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accv[j] += f[j] * wgt;
+            }
+        }
+        chunk_t o;
+        pack8(accv, o);
+        *reinterpret_cast<chunk_t*>(out + pix * C + c * 8) = o;
+    }
+}
+
+// Backward of the above w.r.t. the warped tensor: scatter-add dOut into an fp32 accumulator
+// (grid_sampler_2d_backward).  One lane per channel => every wave-level atomic is 256 contiguous
+// bytes, the shape that runs at the full memory-side atomic rate on gfx950.
+template <typename T>
+__global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ flow, float* __restrict__ dacc,
+                                int N, int H, int W, int C, long long flow_nstride) {
+    const long long total = (long long)N * H * W * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long long pix = idx / C;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
+        const float px = warp_coord((float)x, fp[0], W);
+        const float py = warp_coord((float)y, fp[(long long)H * W], H);
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const float g = (float)dout[idx];
+        float* img = dacc + (long long)n * H * W * C;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+            const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+            if (xi >= 0 && xi < W && yi >= 0 && yi < H) atomicAdd(img + ((long long)yi * W + xi) * C + c, g * wgt);
+        }
+    }
+}
+
+// out = T(a + s)   (a: T or null, s: fp32 or null)
+template <typename T>
+__global__ void add_cast_kernel(const T* __restrict__ a, const float* __restrict__ s, T* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (a) v += (float)a[i];
+        if (s) v += s[i];
+        out[i] = (T)v;
+    }
+}
+
+// planar fp32 -> pixel-major T with C channels (c >= Cin are zero); and back.
+template <typename T>
+__global__ void planar_to_pm_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int Cin, int H, int W, int C) {
+    const long long total = (long long)N * H * W * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long long pix = idx / C;
+        const long long hw = pix % ((long long)H * W);
+        const int n = (int)(pix / ((long long)H * W));
+        out[idx] = (T)(c < Cin ? in[((long long)n * Cin + c) * H * W + hw] : 0.f);
+    }
+}
+template <typename T>
+__global__ void pm_to_planar_kernel(const T* __restrict__ in, float* __restrict__ out, int N, int Cout, int H, int W, int C) {
+    const long long total = (long long)N * Cout * H * W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long hw = idx % ((long long)H * W);
+        const int c = (int)((idx / ((long long)H * W)) % Cout);
+        const int n = (int)(idx / ((long long)H * W * Cout));
+        out[idx] = (float)in[((long long)n * H * W + hw) * C + c];
+    }
+}
+
+// ---- SPyNet plumbing (RealBasicVSR/modules/spynet.py:38-93) -----------------------------------
+__device__ __forceinline__ void src_index(int d, float scale, int in_size, bool align, int& i0, int& i1, float& l1) {
+    float s = align ? d * scale : (d + 0.5f) * scale - 0.5f;
+    if (!align && s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+// frames (F,3,h,w) -> ((bilinear resize to (hu,wu), align_corners=False) - mean) / std   spynet.py:72-80,40-41
+__global__ void resize_norm_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ mean,
+                                   const float* __restrict__ std, int F, int h, int w, int hu, int wu) {
+    const long long total = (long long)F * 3 * hu * wu;
+    const float sy = (float)h / (float)hu, sx = (float)w / (float)wu;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % wu);
+        const int y = (int)((idx / wu) % hu);
+        const int c = (int)((idx / ((long long)wu * hu)) % 3);
+        const long long f = idx / ((long long)wu * hu * 3);
+        int y0, y1, x0, x1; float ly, lx;
+        src_index(y, sy, h, false, y0, y1, ly);
+        src_index(x, sx, w, false, x0, x1, lx);
+        const float* p = in + (f * 3 + c) * (long long)h * w;
+        const float v = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1]) +
+                        ly * ((1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+        out[idx] = (v - mean[c]) / std[c];
+    }
+}
+
+// 2x2 average pool, planar (spynet.py:44-45)
+__global__ void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes, int h, int w) {
+    const int ho = h / 2, wo = w / 2;
+    const long long total = planes * ho * wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % wo);
+        const int y = (int)((idx / wo) % ho);
+        const long long pl = idx / ((long long)wo * ho);
+        const float* p = in + pl * h * w + (long long)(2 * y) * w + 2 * x;
+        out[idx] = 0.25f * (p[0] + p[1] + p[w] + p[w + 1]);
+    }
+}
+
+// One pyramid level's network input (spynet.py:51-63), for all frame pairs at once:
+//   flow_up = level 0 ? 0 : 2 * bilinear_x2(flow_prev, align_corners=True)
+//   x16[p] = [ref(3) | warp(supp, flow_up, border)(3) | flow_up(2) | 0 x 8]      pixel-major, 16 channels
+// Pair p of P = 2*n*(t-1): p < P/2 -> backward flow (ref = frame i, supp = i+1), else forward
+// (ref = frame i+1, supp = i)  (basicvsr.py:32-35).
+template <typename T>
+__global__ void spynet_prepare_kernel(const float* __restrict__ frames, const float* __restrict__ flow_prev,
+                                      float* __restrict__ flow_up, T* __restrict__ x16, int n, int t, int P, int pair_mode,
+                                      int h, int w, int level0) {
+    const long long total = (long long)P * h * w;
+    const int hp = h / 2, wp = w / 2;
+    const float sy = hp > 1 ? (float)(hp - 1) / (float)(h - 1) : 0.f;   // align_corners=True, out = 2*in
+    const float sx = wp > 1 ? (float)(wp - 1) / (float)(w - 1) : 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const int p = (int)(idx / ((long long)w * h));
+        int fref, fsup;
+        if (pair_mode) {            // frames = [ref_0..ref_{P-1}, supp_0..supp_{P-1}]
+            fref = p; fsup = P + p;
+        } else {
+            const int half = P / 2;
+            const int q = p < half ? p : p - half;
+            const int b = q / (t - 1), i = q % (t - 1);
+            fref = p < half ? b * t + i : b * t + i + 1;
+            fsup = p < half ? b * t + i + 1 : b * t + i;
+        }
+        float fu[2] = {0.f, 0.f};
+        if (!level0) {
+            int y0, y1, x0, x1; float ly, lx;
+            src_index(y, sy, hp, true, y0, y1, ly);
+            src_index(x, sx, wp, true, x0, x1, lx);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float* fp = flow_prev + ((long long)p * 2 + c) * hp * wp;
+                fu[c] = 2.0f * ((1.f - ly) * ((1.f - lx) * fp[y0 * wp + x0] + lx * fp[y0 * wp + x1]) +
+                                ly * ((1.f - lx) * fp[y1 * wp + x0] + lx * fp[y1 * wp + x1]));
+            }
+        }
+        const long long hw = (long long)h * w;
+        flow_up[((long long)p * 2 + 0) * hw + (long long)y * w + x] = fu[0];
+        flow_up[((long long)p * 2 + 1) * hw + (long long)y * w + x] = fu[1];
+        // border-mode warp of the supporting frame
+        float px = warp_coord((float)x, fu[0], w), py = warp_coord((float)y, fu[1], h);
+        px = fminf(fmaxf(px, 0.f), (float)(w - 1));
+        py = fminf(fmaxf(py, 0.f), (float)(h - 1));
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const int x1 = x0 + 1 < w ? x0 + 1 : w - 1, y1 = y0 + 1 < h ? y0 + 1 : h - 1;   // weight of a clamped tap is 0
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = frames[((long long)fref * 3 + c) * hw + (long long)y * w + x];
+            const float* sp = frames + ((long long)fsup * 3 + c) * hw;
+            v[3 + c] = wy0 * (wx0 * sp[y0 * w + x0] + wx1 * sp[y0 * w + x1]) + wy1 * (wx0 * sp[y1 * w + x0] + wx1 * sp[y1 * w + x1]);
+        }
+        v[6] = fu[0]; v[7] = fu[1];
+        typename EW<T>::chunk_t lo, hi;
+        float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        pack8(v, lo);
+        pack8(z, hi);
+        typename EW<T>::chunk_t* o = reinterpret_cast<typename EW<T>::chunk_t*>(x16 + idx * 16);
+        o[0] = lo; o[1] = hi;
+    }
+}
+
+// flow at (hu,wu) -> (h,w) bilinear align_corners=False, u *= w/wu, v *= h/hu   (spynet.py:83-91)
+__global__ void flow_out_kernel(const float* __restrict__ in, float* __restrict__ out, int P, int hu, int wu, int h, int w) {
+    const long long total = (long long)P * 2 * h * w;
+    const float sy = (float)hu / (float)h, sx = (float)wu / (float)w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const int c = (int)((idx / ((long long)w * h)) % 2);
+        const long long p = idx / ((long long)w * h * 2);
+        int y0, y1, x0, x1; float ly, lx;
+        src_index(y, sy, hu, false, y0, y1, ly);
+        src_index(x, sx, wu, false, x0, x1, lx);
+        const float* ip = in + (p * 2 + c) * (long long)hu * wu;
+        const float v = (1.f - ly) * ((1.f - lx) * ip[y0 * wu + x0] + lx * ip[y0 * wu + x1]) +
+                        ly * ((1.f - lx) * ip[y1 * wu + x0] + lx * ip[y1 * wu + x1]);
+        out[idx] = v * (c == 0 ? (float)w / (float)wu : (float)h / (float)hu);
+    }
+}
+
+// OIHW fp32 -> packed T [tap][R][Cc] consumed by conv_mfma (A operand rows = R, K = Cc).
+//   mode 0 (forward):  dst[tap][r][c] = w[r*o_mul + o_add][i_off + c][tap]
+//   mode 1 (data grad): dst[tap][r][c] = w[c*o_mul + o_add][i_off + r][KK-1-tap]   (flipped taps, roles swapped)
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ dst, int KK, int RP, int CPd,
+                                    int r_real, int c_real, int I_total, int i_off, int o_mul, int o_add, int mode) {
+    const int total = KK * RP * CPd;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % CPd, r = (idx / CPd) % RP, tap = idx / (CPd * RP);
+    float v = 0.f;
+    if (r < r_real && c < c_real) {
+        if (mode == 0) v = w[((long long)(r * o_mul + o_add) * I_total + i_off + c) * KK + tap];
+        else v = w[((long long)(c * o_mul + o_add) * I_total + i_off + r) * KK + (KK - 1 - tap)];
+    }
+    dst[idx] = (T)v;
+}
+
+__global__ void charbonnier_grad_kernel(const float* __restrict__ sr, const float* __restrict__ hr, float* __restrict__ dsr,
+                                        float* __restrict__ loss_acc, long long n, float eps, float scale) {
+    float local = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = sr[i] - hr[i];
+        const float r = sqrtf(d * d + eps);
+        local += r;
+        dsr[i] = scale * d / r;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, local * scale);
+}
+
+inline int grid_for(long long total, int block = 256) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                              \
+    if ((dtype) == VSR_BF16) { typedef bf16_t T; CALL; }     \
+    else if ((dtype) == VSR_F32) { typedef float T; CALL; }  \
+    else return VSR_ERR_BADARG;
+
+int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out, int N, int H, int W, int C,
+                        long long flow_nstride, hipStream_t st) {
+    if (C % 8) return VSR_ERR_BADARG;
+    const long long total = (long long)N * H * W * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)in, flow, (T*)out, N, H, W, C, flow_nstride));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
+                        long long flow_nstride, hipStream_t st) {
+    const long long total = (long long)N * H * W * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)dout, flow, dacc, N, H, W, C, flow_nstride));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, long long n, hipStream_t st) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(add_cast_kernel<T>, dim3(grid_for(n)), dim3(256), 0, st, (const T*)a, s, (T*)out, n));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_planar_to_pm(int dtype, const float* in, void* out, int N, int Cin, int H, int W, int C, hipStream_t st) {
+    const long long total = (long long)N * H * W * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(planar_to_pm_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, in, (T*)out, N, Cin, H, W, C));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_pm_to_planar(int dtype, const void* in, float* out, int N, int Cout, int H, int W, int C, hipStream_t st) {
+    const long long total = (long long)N * Cout * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pm_to_planar_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)in, out, N, Cout, H, W, C));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_resize_norm(const float* in, float* out, const float* mean, const float* std, int F, int h, int w, int hu, int wu, hipStream_t st) {
+    hipLaunchKernelGGL(resize_norm_kernel, dim3(grid_for((long long)F * 3 * hu * wu)), dim3(256), 0, st, in, out, mean, std, F, h, w, hu, wu);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_avgpool2(const float* in, float* out, long long planes, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(planes * (h / 2) * (w / 2))), dim3(256), 0, st, in, out, planes, h, w);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_spynet_prepare(int dtype, const float* frames, const float* flow_prev, float* flow_up, void* x16,
+                              int n, int t, int P, int pair_mode, int h, int w, int level0, hipStream_t st) {
+    const long long total = (long long)P * h * w;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(spynet_prepare_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, frames, flow_prev, flow_up, (T*)x16, n, t, P, pair_mode, h, w, level0));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_flow_out(const float* in, float* out, int P, int hu, int wu, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(flow_out_kernel, dim3(grid_for((long long)P * 2 * h * w)), dim3(256), 0, st, in, out, P, hu, wu, h, w);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
+                            int I_total, int i_off, int o_mul, int o_add, int mode, hipStream_t st) {
+    const int total = KK * RP * CPd;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, st, w, (T*)dst, KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add, mode));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps, hipStream_t st) {
+    HIP_CHECK_RET(hipMemsetAsync(loss_acc, 0, sizeof(float), st));
+    hipLaunchKernelGGL(charbonnier_grad_kernel, dim3(grid_for(n)), dim3(256), 0, st, sr, hr, dsr, loss_acc, n, eps, 1.0f / (float)n);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}

@@ -1,0 +1,702 @@
+// Whole-clip scheduler for the BasicVSR path: plans one workspace arena, then enqueues every
+// kernel of BasicVSR.forward (basicvsr.py:39-83) and of its backward on one HIP
+// stream.  No allocation, no synchronisation, no global state: the plan is a pure function of the
+// descriptor, so forward and backward recompute identical offsets.
+//
+// Memory-rich by design (288 GB HBM3E): every trunk activation AND every trunk activation-gradient
+// of the clip is retained, so each layer's weight gradient is ONE split-K launch over all t frames
+// (see wgrad_mfma.hip) instead of t launches + t reductions.
+#include <vector>
+#include "kernels.h"
+#include "../../include/vsrlab_hip.h"
+
+namespace {
+
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~size_t(255);
+        return o;
+    }
+};
+
+inline size_t esize(int dtype) { return dtype == VSR_BF16 ? 2 : 4; }
+
+constexpr int C = 64;           // mid channels of the HIP path
+constexpr int NSPY = 5;         // convs per SPyNet level
+const int SPY_CI[NSPY] = {8, 32, 64, 32, 16}, SPY_CO[NSPY] = {32, 64, 32, 16, 2};
+const int SPY_CIP[NSPY] = {16, 32, 64, 32, 16}, SPY_COP[NSPY] = {32, 64, 32, 32, 32};   // padded (template) sizes
+const int SPY_CD[NSPY] = {32, 64, 32, 16, 0};     // channels per pixel of each layer's pixel-major output
+
+struct SpyPlan {
+    int P, F, h, w, hu, wu;
+    size_t pyr[6];          // planar fp32 normalised frames, level 0 = coarsest
+    size_t x16, b32a, b64, b32b, b16;   // pixel-major T at the finest level size
+    size_t flow_a, flow_b, flow_up;     // planar fp32 [P][2][hu][wu]
+    size_t wpack[6][NSPY], bias[6][NSPY];
+    void plan(Bump& b, int P_, int F_, int h_, int w_, int dtype) {
+        P = P_; F = F_; h = h_; w = w_;
+        wu = (w % 32) == 0 ? w : 32 * (w / 32 + 1);      // spynet.py:72-73
+        hu = (h % 32) == 0 ? h : 32 * (h / 32 + 1);
+        const size_t es = esize(dtype);
+        for (int l = 0; l < 6; ++l) {
+            const int s = 5 - l;
+            pyr[l] = b.take((size_t)F * 3 * (hu >> s) * (wu >> s) * 4);
+        }
+        const size_t px = (size_t)P * hu * wu;
+        x16 = b.take(px * 16 * es); b32a = b.take(px * 32 * es); b64 = b.take(px * 64 * es);
+        b32b = b.take(px * 32 * es); b16 = b.take(px * 16 * es);
+        flow_a = b.take(px * 2 * 4); flow_b = b.take(px * 2 * 4); flow_up = b.take(px * 2 * 4);
+        for (int l = 0; l < 6; ++l)
+            for (int j = 0; j < NSPY; ++j) {
+                wpack[l][j] = b.take((size_t)49 * SPY_COP[j] * SPY_CIP[j] * es);
+                bias[l][j] = b.take(64 * 4);
+            }
+    }
+};
+
+struct Plan {
+    VsrBasicVSRDesc d;
+    bool bwd;
+    int rb, n, t, h, w, dtype;
+    size_t es;
+    size_t px1;                 // elements of one (n,h,w,64) tensor
+    // packed weights / biases
+    size_t stem_w[2], stem_wd[2], stem_b[2];
+    std::vector<size_t> blk_w[2], blk_wd[2], blk_b[2];     // [2*rb]: conv1, conv2 alternating
+    size_t point_w, point_wd, point_b;
+    size_t up_w[2], up_wd[2], up_b[2];
+    size_t last0_w, last0_wd, last0_b, last2_w, last2_wd, last2_b;
+    SpyPlan spy;
+    size_t flows;               // fp32 planar [2*n*(t-1)][2][h][w]: first half backward, second half forward
+    // trunk activations: [dir][frame]
+    std::vector<size_t> Wp[2], X[2], A[2];      // X: (rb+1) per frame, A: rb per frame (saved mode)
+    std::vector<size_t> feat[2];                // = X[rb]
+    size_t scratchA, scratchW;                  // inference mode
+    // reconstruction
+    std::vector<size_t> Pt, U0, U1, C0;
+    // backward
+    std::vector<size_t> G0[2], G1[2], DX[2];    // G1: rb per frame, DX: (rb+1) per frame (DX[0] unused -> G0)
+    std::vector<size_t> dFeatB;
+    size_t dFF, S, dWp, G_C0, G_U1, G_U0, G_P, slab;
+    size_t total;
+
+    size_t xoff(int dir, int i, int b) const { return X[dir][(size_t)i * (rb + 1) + b]; }
+    size_t aoff(int dir, int i, int b) const { return A[dir][(size_t)i * rb + b]; }
+    size_t g1off(int dir, int i, int b) const { return G1[dir][(size_t)i * rb + b]; }
+    size_t dxoff(int dir, int i, int b) const { return DX[dir][(size_t)i * (rb + 1) + b]; }
+
+    int build(const VsrBasicVSRDesc& desc, bool need_backward) {
+        d = desc; bwd = need_backward;
+        rb = d.res_blocks; n = d.n; t = d.t; h = d.h; w = d.w; dtype = d.dtype;
+        if (d.mid_channels != C || d.upscale != 4 || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
+        if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+        es = esize(dtype);
+        px1 = (size_t)n * h * w * C;
+        Bump b;
+        const size_t w64 = (size_t)9 * C * C * es;
+        for (int dir = 0; dir < 2; ++dir) {
+            stem_w[dir] = b.take(w64 + (size_t)9 * C * 16 * es);
+            stem_wd[dir] = b.take(w64);
+            stem_b[dir] = b.take(C * 4);
+            blk_w[dir].resize(2 * rb); blk_wd[dir].resize(2 * rb); blk_b[dir].resize(2 * rb);
+            for (int k = 0; k < 2 * rb; ++k) { blk_w[dir][k] = b.take(w64); blk_wd[dir][k] = b.take(w64); blk_b[dir][k] = b.take(C * 4); }
+        }
+        point_w = b.take((size_t)2 * C * C * es); point_wd = b.take((size_t)2 * C * C * es); point_b = b.take(C * 4);
+        for (int k = 0; k < 2; ++k) { up_w[k] = b.take(4 * w64); up_wd[k] = b.take(4 * w64); up_b[k] = b.take(4 * C * 4); }
+        last0_w = b.take(w64); last0_wd = b.take(w64); last0_b = b.take(C * 4);
+        last2_w = b.take((size_t)9 * 32 * C * es); last2_wd = b.take((size_t)9 * C * 16 * es); last2_b = b.take(64 * 4);
+        if (t > 1) spy.plan(b, 2 * n * (t - 1), n * t, h, w, dtype);
+        flows = b.take((size_t)2 * n * (t > 1 ? t - 1 : 1) * 2 * h * w * 4);
+        const size_t a1 = px1 * es;
+        for (int dir = 0; dir < 2; ++dir) {
+            Wp[dir].assign(t, 0); feat[dir].assign(t, 0);
+            if (bwd) {
+                X[dir].assign((size_t)t * (rb + 1), 0); A[dir].assign((size_t)t * rb, 0);
+                for (int i = 0; i < t; ++i) {
+                    Wp[dir][i] = b.take(a1);
+                    for (int k = 0; k <= rb; ++k) X[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
+                    for (int k = 0; k < rb; ++k) A[dir][(size_t)i * rb + k] = b.take(a1);
+                    feat[dir][i] = xoff(dir, i, rb);
+                }
+            } else {
+                for (int i = 0; i < t; ++i) feat[dir][i] = b.take(a1);
+            }
+        }
+        scratchA = b.take(a1); scratchW = b.take(a1);
+        const int nrec = bwd ? t : 1;
+        Pt.assign(t, 0); U0.assign(t, 0); U1.assign(t, 0); C0.assign(t, 0);
+        for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(4 * a1); U1[i] = b.take(16 * a1); C0[i] = b.take(16 * a1); }
+        for (int i = nrec; i < t; ++i) { Pt[i] = Pt[0]; U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; }
+        if (bwd) {
+            for (int dir = 0; dir < 2; ++dir) {
+                G0[dir].assign(t, 0); G1[dir].assign((size_t)t * rb, 0); DX[dir].assign((size_t)t * (rb + 1), 0);
+                for (int i = 0; i < t; ++i) {
+                    G0[dir][i] = b.take(a1);
+                    for (int k = 0; k < rb; ++k) G1[dir][(size_t)i * rb + k] = b.take(a1);
+                    for (int k = 1; k <= rb; ++k) DX[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
+                }
+            }
+            dFeatB.assign(t, 0);
+            for (int i = 0; i < t; ++i) dFeatB[i] = b.take(a1);
+            dFF = b.take(a1); S = b.take(px1 * 4); dWp = b.take(a1);
+            G_C0 = b.take(16 * a1); G_U1 = b.take(16 * a1); G_U0 = b.take(4 * a1); G_P = b.take(a1);
+            int cp, xp, stride;
+            vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
+            slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+        }
+        total = b.off;
+        return VSR_OK;
+    }
+};
+
+#define CK(expr) do { int _s = (expr); if (_s != VSR_OK) return _s; } while (0)
+
+struct Ctx {
+    const Plan& p;
+    char* ws;
+    hipStream_t st;
+    int dtype;
+    void* at(size_t off) const { return ws + off; }
+    const float* fat(size_t off) const { return reinterpret_cast<const float*>(ws + off); }
+
+    ConvArgs base(int N, int H, int W) const {
+        ConvArgs a = {};
+        a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1;
+        a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C; a.dst_nstride = (long long)H * W * C;
+        for (int s = 0; s < VSR_MAX_SRC; ++s) a.src_nstride[s] = (long long)H * W * C;
+        return a;
+    }
+    // y = act(conv3x3(x) + bias) (+res) (*mask(aux)) -- 64 -> 64 at one resolution
+    int conv64(const void* x, size_t wpack, const float* bias, void* y, int act, const void* res, const void* aux, int mask,
+               int N, int H, int W) const {
+        ConvArgs a = base(N, H, W);
+        a.src[0] = x; a.wpack = at(wpack); a.bias = bias; a.dst[0] = y; a.act = act; a.res[0] = res; a.aux[0] = aux; a.mask_mode = mask;
+        return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+    }
+    // conv3x3 64->256 + PixelShuffle(2): x (N,H,W,64) -> y (N,2H,2W,64)   (upsampling.py:10-12)
+    int conv_ps(const void* x, size_t wpack, const float* bias4, void* y, int N, int H, int W) const {
+        ConvArgs a = base(N, H, W);
+        a.src[0] = x; a.wpack = at(wpack); a.w_zstride = 9 * C * C; a.bias = bias4; a.bias_zstride = C; a.nz = 4;
+        a.out_step = 2; a.Hd = 2 * H; a.Wd = 2 * W; a.dst_nstride = (long long)4 * H * W * C;
+        for (int z = 0; z < 4; ++z) { a.dst[z] = y; a.out_oy[z] = z >> 1; a.out_ox[z] = z & 1; }
+        return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+    }
+    // data gradient of the above: dy (N,2H,2W,64) -> dx (N,H,W,64) (* mask(aux))
+    int conv_ps_dgrad(const void* dy, size_t wpackd, void* dx, const void* aux, int mask, int N, int H, int W) const {
+        ConvArgs a = base(N, H, W);
+        a.nz = 1; a.in_step = 2; a.Hs = 2 * H; a.Ws = 2 * W;
+        for (int s = 0; s < 4; ++s) { a.src[s] = dy; a.src_oy[s] = s >> 1; a.src_ox[s] = s & 1; a.src_nstride[s] = (long long)4 * H * W * C; }
+        a.wpack = at(wpackd); a.dst[0] = dx; a.aux[0] = aux; a.mask_mode = mask;
+        return vsr_launch_conv(dtype, 3, 4, 64, 64, 0, 64, EPI_NHWC, a, st);
+    }
+    int pack(const float* w, size_t dst, int KK, int RP, int CPd, int r_real, int c_real, int I_total, int i_off, int o_mul,
+             int o_add, int mode) const {
+        return vsr_launch_pack_weights(dtype, w, at(dst), KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add, mode, st);
+    }
+    int pack_bias(const float* b, size_t dst, int nreal, int o_mul = 1, int o_add = 0) const {
+        return vsr_launch_pack_weights(VSR_F32, b, at(dst), 1, nreal, 1, nreal, 1, 1, 0, o_mul, o_add, 0, st);
+    }
+};
+
+// parameter index helpers (order documented in vsrlab_hip.h)
+struct PIdx {
+    int rb;
+    int trunk_base(int dir) const { return dir * (2 + 4 * rb); }
+    int stem_w(int dir) const { return trunk_base(dir); }
+    int stem_b(int dir) const { return trunk_base(dir) + 1; }
+    int blk_w(int dir, int k) const { return trunk_base(dir) + 2 + 2 * k; }      // k = 2*block + (conv2 ? 1 : 0)
+    int blk_b(int dir, int k) const { return trunk_base(dir) + 3 + 2 * k; }
+    int point_w() const { return 2 * (2 + 4 * rb); }
+    int point_b() const { return point_w() + 1; }
+    int up_w(int k) const { return point_w() + 2 + 2 * k; }
+    int up_b(int k) const { return up_w(k) + 1; }
+    int last0_w() const { return point_w() + 6; }
+    int last0_b() const { return point_w() + 7; }
+    int last2_w() const { return point_w() + 8; }
+    int last2_b() const { return point_w() + 9; }
+    int spy_base() const { return point_w() + 10; }
+    int spy_w(int lvl, int j) const { return spy_base() + (lvl * NSPY + j) * 2; }
+    int spy_b(int lvl, int j) const { return spy_w(lvl, j) + 1; }
+    int spy_mean() const { return spy_base() + 60; }
+    int spy_std() const { return spy_base() + 61; }
+    int count() const { return spy_base() + 62; }
+};
+
+// ---- SPyNet (spynet.py:38-93) for P frame pairs ------------------------------------------------
+// frames: planar fp32 (F,3,h,w).  pair_mode 0: BasicVSR pairing over (n,t) (basicvsr.py:32-35);
+// pair_mode 1: frames = [ref_0..ref_{P-1}, supp_0..supp_{P-1}].
+int spynet_pack(const Ctx& c, const SpyPlan& sp, const float* const* params, int base_idx) {
+    for (int l = 0; l < 6; ++l)
+        for (int j = 0; j < NSPY; ++j) {
+            const float* w = params[base_idx + (l * NSPY + j) * 2];
+            const float* b = params[base_idx + (l * NSPY + j) * 2 + 1];
+            CK(c.pack(w, sp.wpack[l][j], 49, SPY_COP[j], SPY_CIP[j], SPY_CO[j], SPY_CI[j], SPY_CI[j], 0, 1, 0, 0));
+            CK(c.pack_bias(b, sp.bias[l][j], SPY_CO[j]));
+        }
+    return VSR_OK;
+}
+
+int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float* mean, const float* std, int n, int t,
+               int pair_mode, float* flows_out) {
+    const int P = sp.P, F = sp.F, hu = sp.hu, wu = sp.wu;
+    CK(vsr_launch_resize_norm(frames, (float*)c.at(sp.pyr[5]), mean, std, F, sp.h, sp.w, hu, wu, c.st));
+    for (int l = 5; l > 0; --l)
+        CK(vsr_launch_avgpool2(c.fat(sp.pyr[l]), (float*)c.at(sp.pyr[l - 1]), (long long)F * 3, hu >> (5 - l), wu >> (5 - l), c.st));
+    size_t fprev = sp.flow_a, fcur = sp.flow_b;
+    for (int l = 0; l < 6; ++l) {
+        const int hl = hu >> (5 - l), wl = wu >> (5 - l);
+        CK(vsr_launch_spynet_prepare(c.dtype, c.fat(sp.pyr[l]), l == 0 ? nullptr : c.fat(fprev), (float*)c.at(sp.flow_up), c.at(sp.x16),
+                                     n, t, P, pair_mode, hl, wl, l == 0, c.st));
+        const size_t bufs[NSPY + 1] = {sp.x16, sp.b32a, sp.b64, sp.b32b, sp.b16, 0};
+        for (int j = 0; j < NSPY; ++j) {
+            ConvArgs a = c.base(P, hl, wl);
+            a.src[0] = c.at(bufs[j]); a.src_nstride[0] = (long long)hl * wl * SPY_CIP[j];
+            a.wpack = c.at(sp.wpack[l][j]); a.bias = c.fat(sp.bias[l][j]); a.act = ACT_RELU;   // ReLU after the LAST conv too (spynet.py:16-18)
+            a.cout_real = SPY_CO[j];
+            if (j < NSPY - 1) {
+                a.dst[0] = c.at(bufs[j + 1]); a.CD = SPY_CD[j]; a.dst_nstride = (long long)hl * wl * SPY_CD[j];
+                CK(vsr_launch_conv(c.dtype, 7, 1, SPY_CIP[j], SPY_CIP[j], 0, SPY_COP[j], EPI_NHWC, a, c.st));
+            } else {
+                a.dst[0] = c.at(fcur); a.dst_nstride = (long long)2 * hl * wl; a.pres = c.fat(sp.flow_up);   // flow = flow_up + residue (spynet.py:65)
+                CK(vsr_launch_conv(c.dtype, 7, 1, 16, 16, 0, 32, EPI_PLANAR, a, c.st));
+            }
+        }
+        size_t tmp = fprev; fprev = fcur; fcur = tmp;
+    }
+    return vsr_launch_flow_out(c.fat(fprev), flows_out, P, hu, wu, sp.h, sp.w, c.st);
+}
+
+int pack_all(const Ctx& c, const Plan& p, const float* const* prm) {
+    const PIdx ix{p.rb};
+    const int dt = c.dtype; (void)dt;
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* sw = prm[ix.stem_w(dir)];
+        // cat([lr_i(3), feat(64)]) (basicvsr.py:56,71): source 0 = feat = input channels 3..66, source 1 = LR = 0..2
+        CK(c.pack(sw, p.stem_w[dir], 9, C, C, C, C, C + 3, 3, 1, 0, 0));
+        CK(c.pack(sw, p.stem_w[dir] + (size_t)9 * C * C * p.es, 9, C, 16, C, 3, C + 3, 0, 1, 0, 0));
+        CK(c.pack_bias(prm[ix.stem_b(dir)], p.stem_b[dir], C));
+        if (p.bwd) CK(c.pack(sw, p.stem_wd[dir], 9, C, C, C, C, C + 3, 3, 1, 0, 1));
+        for (int k = 0; k < 2 * p.rb; ++k) {
+            CK(c.pack(prm[ix.blk_w(dir, k)], p.blk_w[dir][k], 9, C, C, C, C, C, 0, 1, 0, 0));
+            if (p.bwd) CK(c.pack(prm[ix.blk_w(dir, k)], p.blk_wd[dir][k], 9, C, C, C, C, C, 0, 1, 0, 1));
+            CK(c.pack_bias(prm[ix.blk_b(dir, k)], p.blk_b[dir][k], C));
+        }
+    }
+    for (int s = 0; s < 2; ++s) {
+        CK(c.pack(prm[ix.point_w()], p.point_w + (size_t)s * C * C * p.es, 1, C, C, C, C, 2 * C, s * C, 1, 0, 0));
+        if (p.bwd) CK(c.pack(prm[ix.point_w()], p.point_wd + (size_t)s * C * C * p.es, 1, C, C, C, C, 2 * C, s * C, 1, 0, 1));
+    }
+    CK(c.pack_bias(prm[ix.point_b()], p.point_b, C));
+    for (int k = 0; k < 2; ++k)
+        for (int z = 0; z < 4; ++z) {
+            // PixelShuffle(2): out[c, 2y+i, 2x+j] = conv[4c+2i+j, y, x]  => sub-conv z uses rows 4c+z
+            CK(c.pack(prm[ix.up_w(k)], p.up_w[k] + (size_t)z * 9 * C * C * p.es, 9, C, C, C, C, C, 0, 4, z, 0));
+            if (p.bwd) CK(c.pack(prm[ix.up_w(k)], p.up_wd[k] + (size_t)z * 9 * C * C * p.es, 9, C, C, C, C, C, 0, 4, z, 1));
+            CK(c.pack_bias(prm[ix.up_b(k)], p.up_b[k] + (size_t)z * C * 4, C, 4, z));
+        }
+    CK(c.pack(prm[ix.last0_w()], p.last0_w, 9, C, C, C, C, C, 0, 1, 0, 0));
+    if (p.bwd) CK(c.pack(prm[ix.last0_w()], p.last0_wd, 9, C, C, C, C, C, 0, 1, 0, 1));
+    CK(c.pack_bias(prm[ix.last0_b()], p.last0_b, C));
+    CK(c.pack(prm[ix.last2_w()], p.last2_w, 9, 32, C, 3, C, C, 0, 1, 0, 0));
+    if (p.bwd) CK(c.pack(prm[ix.last2_w()], p.last2_wd, 9, C, 16, C, 3, C, 0, 1, 0, 1));
+    CK(c.pack_bias(prm[ix.last2_b()], p.last2_b, 3));
+    if (p.t > 1) CK(spynet_pack(c, p.spy, prm, ix.spy_base()));
+    return VSR_OK;
+}
+
+// one call of ResidualBlock (conv.py:94-103) on cat([lr_i, warped feat])
+int trunk_forward(const Ctx& c, const Plan& p, int dir, int i, const void* warped, const float* lrs) {
+    const int n = p.n, h = p.h, w = p.w, rb = p.rb;
+    void* x = p.bwd ? c.at(p.xoff(dir, i, 0)) : c.at(p.feat[dir][i]);
+    {
+        ConvArgs a = c.base(n, h, w);
+        a.src[0] = warped;                                   // null => zeros (first frame of the direction)
+        a.src[1] = lrs + (size_t)i * 3 * h * w; a.src_nstride[1] = (long long)p.t * 3 * h * w;
+        a.wpack = c.at(p.stem_w[dir]); a.bias = c.fat(p.stem_b[dir]); a.dst[0] = x; a.act = ACT_LEAKY;
+        CK(vsr_launch_conv(c.dtype, 3, 2, 64, 16, 1, 64, EPI_NHWC, a, c.st));
+    }
+    for (int b = 0; b < rb; ++b) {      // x + conv2(relu(conv1(x)))   (conv.py:89-92)
+        void* act = p.bwd ? c.at(p.aoff(dir, i, b)) : c.at(p.scratchA);
+        void* xn = p.bwd ? c.at(p.xoff(dir, i, b + 1)) : x;   // inference: in place (residual read = own pixel)
+        CK(c.conv64(x, p.blk_w[dir][2 * b], c.fat(p.blk_b[dir][2 * b]), act, ACT_RELU, nullptr, nullptr, 0, n, h, w));
+        CK(c.conv64(act, p.blk_w[dir][2 * b + 1], c.fat(p.blk_b[dir][2 * b + 1]), xn, ACT_NONE, x, nullptr, 0, n, h, w));
+        x = xn;
+    }
+    return VSR_OK;
+}
+
+int recon_forward(const Ctx& c, const Plan& p, int i, const float* lrs, float* sr) {
+    const int n = p.n, h = p.h, w = p.w;
+    {
+        ConvArgs a = c.base(n, h, w);       // point_conv on cat([outputs[i], feat_prop]) (basicvsr.py:75-77)
+        a.src[0] = c.at(p.feat[0][i]); a.src[1] = c.at(p.feat[1][i]);
+        a.wpack = c.at(p.point_w); a.bias = c.fat(p.point_b); a.dst[0] = c.at(p.Pt[i]); a.act = ACT_LEAKY;
+        CK(vsr_launch_conv(c.dtype, 1, 2, 64, 64, 0, 64, EPI_NHWC, a, c.st));
+    }
+    CK(c.conv_ps(c.at(p.Pt[i]), p.up_w[0], c.fat(p.up_b[0]), c.at(p.U0[i]), n, h, w));
+    CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), n, 2 * h, 2 * w));
+    CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, n, 4 * h, 4 * w));
+    {
+        ConvArgs a = c.base(n, 4 * h, 4 * w);   // conv_last.2 + bilinear x4 skip (basicvsr.py:21-22,82)
+        a.src[0] = c.at(p.C0[i]); a.wpack = c.at(p.last2_w); a.bias = c.fat(p.last2_b); a.cout_real = 3;
+        a.dst[0] = sr + (size_t)i * 3 * 16 * h * w; a.dst_nstride = (long long)p.t * 3 * 16 * h * w;
+        a.base_lr = lrs + (size_t)i * 3 * h * w; a.base_nstride = (long long)p.t * 3 * h * w; a.base_h = h; a.base_w = w;
+        CK(vsr_launch_conv(c.dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, c.st));
+    }
+    return VSR_OK;
+}
+
+const float* flow_ptr(const Ctx& c, const Plan& p, int forward, int i) {   // flow of pair i, batch stride (t-1)*2*h*w
+    return c.fat(p.flows) + ((size_t)forward * p.n * (p.t - 1) + i) * 2 * p.h * p.w;
+}
+
+int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float* sr, char* ws, hipStream_t st) {
+    const Ctx c{p, ws, st, p.dtype};
+    const PIdx ix{p.rb};
+    const int n = p.n, t = p.t, h = p.h, w = p.w;
+    const long long fstride = (long long)(t - 1) * 2 * h * w;
+    CK(pack_all(c, p, prm));
+    if (t > 1) CK(spynet_run(c, p.spy, lrs, prm[ix.spy_mean()], prm[ix.spy_std()], n, t, 0, (float*)c.at(p.flows)));
+    // backward-time propagation (basicvsr.py:46-60)
+    for (int i = t - 1; i >= 0; --i) {
+        void* warped = nullptr;
+        if (i < t - 1) {
+            warped = p.bwd ? c.at(p.Wp[0][i]) : c.at(p.scratchW);
+            CK(vsr_launch_warp_fwd(c.dtype, c.at(p.feat[0][i + 1]), flow_ptr(c, p, 0, i), warped, n, h, w, C, fstride, st));
+        }
+        CK(trunk_forward(c, p, 0, i, warped, lrs));
+    }
+    // forward-time propagation + reconstruction (basicvsr.py:62-82)
+    for (int i = 0; i < t; ++i) {
+        void* warped = nullptr;
+        if (i > 0) {
+            warped = p.bwd ? c.at(p.Wp[1][i]) : c.at(p.scratchW);
+            CK(vsr_launch_warp_fwd(c.dtype, c.at(p.feat[1][i - 1]), flow_ptr(c, p, 1, i - 1), warped, n, h, w, C, fstride, st));
+        }
+        CK(trunk_forward(c, p, 1, i, warped, lrs));
+        CK(recon_forward(c, p, i, lrs, sr));
+    }
+    return VSR_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+struct WG {   // one weight-gradient launch + reduction
+    const Ctx& c;
+    int run(int ks, int cx, bool xp, int cout, bool dyp, WgradArgs& a, int cout_real, int cin_real, float* gw, int I_total,
+            int i_off, int o_mul, int o_add, float* gb) const {
+        if (!gw && !gb) return VSR_OK;
+        int cp, xpd, stride;
+        vsr_wgrad_slab_dims(ks, cx, cout, &cp, &xpd, &stride);
+        a.slab = (float*)c.at(c.p.slab); a.slab_stride = stride;
+        const int tiles = a.N * cdiv(a.H, 8) * cdiv(a.W, 32);
+        const int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
+        CK(vsr_launch_wgrad(c.dtype, ks, cx, xp, cout, dyp, a, nwg, c.st));
+        if (!gw) return VSR_ERR_BADARG;
+        return vsr_launch_wgrad_reduce(a.slab, nwg, ks, cx, cout, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, 1, c.st);
+    }
+};
+
+WgradArgs wg_base(int N, int H, int W) {
+    WgradArgs a = {};
+    a.N = N; a.H = H; a.W = W; a.nseg = 1;
+    a.x_step = 1; a.Hx = H; a.Wx = W; a.x_nstride = (long long)H * W * C;
+    a.dy_step = 1; a.Hy = H; a.Wy = W; a.dy_nstride = (long long)H * W * C;
+    return a;
+}
+
+int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g) {
+    const PIdx ix{p.rb};
+    const WG wg{c};
+    const int n = p.n, h = p.h, w = p.w, H4 = 4 * h, W4 = 4 * w;
+    const float* dsr_i = dsr + (size_t)i * 3 * H4 * W4;
+    const long long dsr_ns = (long long)p.t * 3 * H4 * W4;
+    {   // d(conv_last.0 pre-activation) = dgrad(conv_last.2)(dsr) * LeakyReLU'(C0)
+        ConvArgs a = c.base(n, H4, W4);
+        a.src[0] = dsr_i; a.src_nstride[0] = dsr_ns; a.wpack = c.at(p.last2_wd); a.dst[0] = c.at(p.G_C0);
+        a.aux[0] = c.at(p.C0[i]); a.mask_mode = MASK_LEAKY;
+        CK(vsr_launch_conv(c.dtype, 3, 1, 16, 16, 1, 64, EPI_NHWC, a, c.st));
+    }
+    {   // conv_last.2: X = C0, dY = dsr (planar)
+        WgradArgs a = wg_base(n, H4, W4);
+        a.x[0] = c.at(p.C0[i]); a.dy[0] = dsr_i; a.dy_nstride = dsr_ns;
+        CK(wg.run(3, 64, false, 16, true, a, 3, C, g[ix.last2_w()], C, 0, 1, 0, g[ix.last2_b()]));
+    }
+    CK(c.conv64(c.at(p.G_C0), p.last0_wd, nullptr, c.at(p.G_U1), ACT_NONE, nullptr, nullptr, 0, n, H4, W4));
+    {   // conv_last.0: X = U1, dY = G_C0
+        WgradArgs a = wg_base(n, H4, W4);
+        a.x[0] = c.at(p.U1[i]); a.dy[0] = c.at(p.G_C0);
+        CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.last0_w()], C, 0, 1, 0, g[ix.last0_b()]));
+    }
+    // upsample.1 (at 2h x 2w): dgrad, then wgrad per pixel-shuffle phase z
+    CK(c.conv_ps_dgrad(c.at(p.G_U1), p.up_wd[1], c.at(p.G_U0), nullptr, 0, n, 2 * h, 2 * w));
+    for (int z = 0; z < 4; ++z) {
+        WgradArgs a = wg_base(n, 2 * h, 2 * w);
+        a.x[0] = c.at(p.U0[i]); a.dy[0] = c.at(p.G_U1);
+        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = H4; a.Wy = W4; a.dy_nstride = (long long)H4 * W4 * C;
+        CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(1)], C, 0, 4, z, g[ix.up_b(1)]));
+    }
+    // upsample.0 (at h x w): its input is LeakyReLU(point_conv) => mask with P
+    CK(c.conv_ps_dgrad(c.at(p.G_U0), p.up_wd[0], c.at(p.G_P), c.at(p.Pt[i]), MASK_LEAKY, n, h, w));
+    for (int z = 0; z < 4; ++z) {
+        WgradArgs a = wg_base(n, h, w);
+        a.x[0] = c.at(p.Pt[i]); a.dy[0] = c.at(p.G_U0);
+        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = 2 * h; a.Wy = 2 * w; a.dy_nstride = (long long)4 * h * w * C;
+        CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(0)], C, 0, 4, z, g[ix.up_b(0)]));
+    }
+    {   // point_conv dgrad: two 64-channel outputs (d outputs[i], d feat_prop)
+        ConvArgs a = c.base(n, h, w);
+        a.src[0] = c.at(p.G_P); a.wpack = c.at(p.point_wd); a.w_zstride = C * C; a.nz = 2;
+        a.dst[0] = c.at(p.dFeatB[i]); a.dst[1] = c.at(p.dFF);
+        CK(vsr_launch_conv(c.dtype, 1, 1, 64, 64, 0, 64, EPI_NHWC, a, c.st));
+    }
+    for (int s = 0; s < 2; ++s) {
+        WgradArgs a = wg_base(n, h, w);
+        a.x[0] = c.at(p.feat[s][i]); a.dy[0] = c.at(p.G_P);
+        CK(wg.run(1, 64, false, 64, false, a, C, C, g[ix.point_w()], 2 * C, s * C, 1, 0, s == 0 ? g[ix.point_b()] : nullptr));
+    }
+    return VSR_OK;
+}
+
+// BPTT through one ResidualBlock call; top gradient = dtop (T) + S (fp32 scatter, optional)
+int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, bool add_scatter, bool has_warp) {
+    const int n = p.n, h = p.h, w = p.w, rb = p.rb;
+    CK(vsr_launch_add_cast(c.dtype, dtop, add_scatter ? c.fat(p.S) : nullptr, c.at(p.dxoff(dir, i, rb)), (long long)p.px1, c.st));
+    for (int b = rb - 1; b >= 0; --b) {
+        const void* dxn = c.at(p.dxoff(dir, i, b + 1));
+        // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
+        CK(c.conv64(dxn, p.blk_wd[dir][2 * b + 1], nullptr, c.at(p.g1off(dir, i, b)), ACT_NONE, nullptr, c.at(p.aoff(dir, i, b)), MASK_RELU, n, h, w));
+        // dX_b = dX_{b+1} + dgrad(conv1)(dA); for b == 0 also through the stem's LeakyReLU
+        void* out = b > 0 ? c.at(p.dxoff(dir, i, b)) : c.at(p.G0[dir][i]);
+        CK(c.conv64(c.at(p.g1off(dir, i, b)), p.blk_wd[dir][2 * b], nullptr, out, ACT_NONE, dxn, b == 0 ? c.at(p.xoff(dir, i, 0)) : nullptr,
+                    b == 0 ? MASK_LEAKY : 0, n, h, w));
+    }
+    if (has_warp)   // gradient w.r.t. the warped state (feat part of the stem's input)
+        CK(c.conv64(c.at(p.G0[dir][i]), p.stem_wd[dir], nullptr, c.at(p.dWp), ACT_NONE, nullptr, nullptr, 0, n, h, w));
+    return VSR_OK;
+}
+
+int trunk_wgrads(const Ctx& c, const Plan& p, int dir, const float* lrs, float* const* g) {
+    const PIdx ix{p.rb};
+    const WG wg{c};
+    const int n = p.n, t = p.t, h = p.h, w = p.w, rb = p.rb;
+    for (int i0 = 0; i0 < t; i0 += VSR_WG_MAXSEG) {
+        const int i1 = i0 + VSR_WG_MAXSEG < t ? i0 + VSR_WG_MAXSEG : t;
+        {   // stem, LR part (+ bias)
+            WgradArgs a = wg_base(n, h, w);
+            a.nseg = 0;
+            for (int i = i0; i < i1; ++i) { a.x[a.nseg] = lrs + (size_t)i * 3 * h * w; a.dy[a.nseg] = c.at(p.G0[dir][i]); ++a.nseg; }
+            a.x_nstride = (long long)t * 3 * h * w;
+            CK(wg.run(3, 16, true, 64, false, a, C, 3, g[ix.stem_w(dir)], C + 3, 0, 1, 0, g[ix.stem_b(dir)]));
+        }
+        {   // stem, feat part: only frames that had a warped state
+            WgradArgs a = wg_base(n, h, w);
+            a.nseg = 0;
+            for (int i = i0; i < i1; ++i) {
+                const bool has = dir == 0 ? (i < t - 1) : (i > 0);
+                if (has) { a.x[a.nseg] = c.at(p.Wp[dir][i]); a.dy[a.nseg] = c.at(p.G0[dir][i]); ++a.nseg; }
+            }
+            if (a.nseg) CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.stem_w(dir)], C + 3, 3, 1, 0, nullptr));
+        }
+        for (int b = 0; b < rb; ++b) {
+            WgradArgs a1 = wg_base(n, h, w), a2 = wg_base(n, h, w);
+            a1.nseg = a2.nseg = 0;
+            for (int i = i0; i < i1; ++i) {
+                a1.x[a1.nseg] = c.at(p.xoff(dir, i, b)); a1.dy[a1.nseg] = c.at(p.g1off(dir, i, b)); ++a1.nseg;
+                a2.x[a2.nseg] = c.at(p.aoff(dir, i, b)); a2.dy[a2.nseg] = c.at(p.dxoff(dir, i, b + 1)); ++a2.nseg;
+            }
+            CK(wg.run(3, 64, false, 64, false, a1, C, C, g[ix.blk_w(dir, 2 * b)], C, 0, 1, 0, g[ix.blk_b(dir, 2 * b)]));
+            CK(wg.run(3, 64, false, 64, false, a2, C, C, g[ix.blk_w(dir, 2 * b + 1)], C, 0, 1, 0, g[ix.blk_b(dir, 2 * b + 1)]));
+        }
+    }
+    return VSR_OK;
+}
+
+int backward_impl(const Plan& p, const float* const* prm, float* const* g, const float* lrs, const float* dsr, char* ws,
+                  hipStream_t st) {
+    (void)prm;
+    const Ctx c{p, ws, st, p.dtype};
+    const int n = p.n, t = p.t, h = p.h, w = p.w;
+    const long long fstride = (long long)(t - 1) * 2 * h * w;
+    // reconstruction + forward-time trunk, last frame first
+    for (int i = t - 1; i >= 0; --i) {
+        CK(recon_backward(c, p, i, lrs, dsr, g));
+        CK(trunk_backward(c, p, 1, i, c.at(p.dFF), i < t - 1, i > 0));
+        if (i > 0) {   // feat_prop(i) = trunk(warp(feat_prop(i-1), flow_forward[i-1]))
+            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.px1 * 4, st));
+            CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp), flow_ptr(c, p, 1, i - 1), (float*)c.at(p.S), n, h, w, C, fstride, st));
+        }
+    }
+    // backward-time trunk: state flows t-1 -> 0, so its gradient flows 0 -> t-1
+    for (int i = 0; i < t; ++i) {
+        CK(trunk_backward(c, p, 0, i, c.at(p.dFeatB[i]), i > 0, i < t - 1));
+        if (i < t - 1) {   // feat_prop(i) = trunk(warp(feat_prop(i+1), flow_backward[i]))
+            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.px1 * 4, st));
+            CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp), flow_ptr(c, p, 0, i), (float*)c.at(p.S), n, h, w, C, fstride, st));
+        }
+    }
+    for (int dir = 0; dir < 2; ++dir) CK(trunk_wgrads(c, p, dir, lrs, g));
+    return VSR_OK;
+}
+
+}  // namespace
+
+// ================================ C ABI =========================================================
+extern "C" {
+
+int vsr_abi_version(void) { return 1; }
+
+const char* vsr_status_string(int s) {
+    switch (s) {
+        case VSR_OK: return "ok";
+        case VSR_ERR_BADARG: return "bad argument";
+        case VSR_ERR_UNSUPPORTED: return "unsupported shape/configuration for the HIP path";
+        case VSR_ERR_HIP: return "HIP runtime error";
+        case VSR_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+int vsr_basicvsr_num_params(const VsrBasicVSRDesc* d) {
+    if (!d || d->res_blocks < 0) return VSR_ERR_BADARG;
+    return PIdx{d->res_blocks}.count();
+}
+
+size_t vsr_basicvsr_workspace_bytes(const VsrBasicVSRDesc* d, int need_backward) {
+    if (!d) return 0;
+    Plan p;
+    if (p.build(*d, need_backward != 0) != VSR_OK) return 0;
+    return p.total;
+}
+
+int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, int nparams, const float* lrs, float* sr,
+                         void* workspace, size_t workspace_bytes, int need_backward, void* stream) {
+    if (!d || !params || !lrs || !sr || !workspace) return VSR_ERR_BADARG;
+    Plan p;
+    CK(p.build(*d, need_backward != 0));
+    if (nparams != PIdx{p.rb}.count()) return VSR_ERR_BADARG;
+    for (int k = 0; k < nparams; ++k) if (!params[k]) return VSR_ERR_BADARG;
+    if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
+    return forward_impl(p, params, lrs, sr, (char*)workspace, (hipStream_t)stream);
+}
+
+int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads, int nparams,
+                          const float* lrs, const float* dsr, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !grads || !lrs || !dsr || !workspace) return VSR_ERR_BADARG;
+    Plan p;
+    CK(p.build(*d, true));
+    if (nparams != PIdx{p.rb}.count()) return VSR_ERR_BADARG;
+    if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
+    return backward_impl(p, params, grads, lrs, dsr, (char*)workspace, (hipStream_t)stream);
+}
+
+int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, float* flow_forward, float* flow_backward, void* stream) {
+    if (!d || !workspace) return VSR_ERR_BADARG;
+    Plan p;
+    CK(p.build(*d, false));     // weight/flow offsets do not depend on need_backward
+    if (p.t < 2) return VSR_OK;
+    const size_t half = (size_t)p.n * (p.t - 1) * 2 * p.h * p.w * 4;
+    const char* f = (const char*)workspace + p.flows;
+    if (flow_backward) HIP_CHECK_RET(hipMemcpyAsync(flow_backward, f, half, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (flow_forward) HIP_CHECK_RET(hipMemcpyAsync(flow_forward, f + half, half, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VSR_OK;
+}
+
+// ---- SPyNet alone ---------------------------------------------------------------------------------
+struct SpyAlone { SpyPlan sp; size_t frames; size_t total; };
+static SpyAlone spy_alone_plan(int N, int h, int w, int dtype) {
+    SpyAlone s; Bump b;
+    s.frames = b.take((size_t)2 * N * 3 * h * w * 4);
+    s.sp.plan(b, N, 2 * N, h, w, dtype);
+    s.total = b.off;
+    return s;
+}
+
+size_t vsr_spynet_workspace_bytes(int N, int h, int w, int dtype) {
+    if (N < 1 || h < 1 || w < 1) return 0;
+    return spy_alone_plan(N, h, w, dtype).total;
+}
+
+int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* params, int nparams, const float* ref,
+                       const float* supp, float* flow, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 1 || h < 1 || w < 1 || !params || nparams != 62 || !ref || !supp || !flow || !workspace) return VSR_ERR_BADARG;
+    if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+    const SpyAlone s = spy_alone_plan(N, h, w, dtype);
+    if (workspace_bytes < s.total) return VSR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Plan dummy; dummy.es = esize(dtype);
+    const Ctx c{dummy, (char*)workspace, st, dtype};
+    const size_t fb = (size_t)N * 3 * h * w * 4;
+    HIP_CHECK_RET(hipMemcpyAsync(c.at(s.frames), ref, fb, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK_RET(hipMemcpyAsync((char*)c.at(s.frames) + fb, supp, fb, hipMemcpyDeviceToDevice, st));
+    CK(spynet_pack(c, s.sp, params, 0));
+    return spynet_run(c, s.sp, c.fat(s.frames), params[60], params[61], N, 2, 1, flow);
+}
+
+// ---- per-op entry points -------------------------------------------------------------------------
+int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H, int W, int Cc, void* stream) {
+    return vsr_launch_warp_fwd(dtype, in_pm, flow, out_pm, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
+}
+int vsr_flow_warp_bwd(int dtype, const void* dout_pm, const float* flow, float* dacc, int N, int H, int W, int Cc, void* stream) {
+    return vsr_launch_warp_bwd(dtype, dout_pm, flow, dacc, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
+}
+int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int Cc, void* stream) {
+    return vsr_launch_planar_to_pm(dtype, in, out_pm, N, Cin, H, W, Cc, (hipStream_t)stream);
+}
+int vsr_pm_to_planar(int dtype, const void* in_pm, float* out, int N, int Cout, int H, int W, int Cc, void* stream) {
+    return vsr_launch_pm_to_planar(dtype, in_pm, out, N, Cout, H, W, Cc, (hipStream_t)stream);
+}
+
+static ConvArgs plain64(const void* x, const void* wpack, const float* b, void* y, int N, int H, int W) {
+    ConvArgs a = {};
+    a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1; a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C;
+    a.dst_nstride = (long long)H * W * C; a.src_nstride[0] = (long long)H * W * C;
+    a.src[0] = x; a.wpack = wpack; a.bias = b; a.dst[0] = y;
+    return a;
+}
+
+int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float* b, void* wpack, void* y_pm, const void* res_pm,
+                        int act, int N, int H, int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CK(vsr_launch_pack_weights(dtype, w, wpack, 9, C, C, C, C, C, 0, 1, 0, 0, st));
+    ConvArgs a = plain64(x_pm, wpack, b, y_pm, N, H, W);
+    a.act = act; a.res[0] = res_pm;
+    return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+}
+
+int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm, const void* res_pm,
+                          const void* aux_pm, int mask_mode, int N, int H, int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CK(vsr_launch_pack_weights(dtype, w, wpack, 9, C, C, C, C, C, 0, 1, 0, 1, st));
+    ConvArgs a = plain64(dy_pm, wpack, nullptr, dx_pm, N, H, W);
+    a.res[0] = res_pm; a.aux[0] = aux_pm; a.mask_mode = mask_mode;
+    return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+}
+
+size_t vsr_conv3x3_c64_wgrad_slab_floats(void) {
+    int cp, xp, stride;
+    vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
+    return (size_t)VSR_WGRAD_NWG * stride;
+}
+
+int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float* gw, float* gb, float* slab, int N, int H, int W,
+                          void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a = wg_base(N, H, W);
+    a.x[0] = x_pm; a.dy[0] = dy_pm;
+    int cp, xp, stride;
+    vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
+    a.slab = slab; a.slab_stride = stride;
+    const int tiles = N * cdiv(H, 8) * cdiv(W, 32);
+    const int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
+    CK(vsr_launch_wgrad(dtype, 3, 64, 0, 64, 0, a, nwg, st));
+    return vsr_launch_wgrad_reduce(slab, nwg, 3, 64, 64, C, C, gw, C, 0, 1, 0, gb, 0, st);
+}
+
+int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, long long numel, float eps, void* stream) {
+    if (!sr || !hr || !dsr || !loss || numel < 1) return VSR_ERR_BADARG;
+    return vsr_launch_charbonnier_grad(sr, hr, dsr, loss, numel, eps, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// Internal C++ launch interface between the engine / C-ABI layer and the kernel translation units.
+#pragma once
+#include "common.h"
+
+int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar, int cout_t, int epi,
+                    const ConvArgs& a, hipStream_t st);
+void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride);
+int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar, const WgradArgs& a, int nwg,
+                     hipStream_t st);
+int vsr_launch_wgrad_reduce(const float* slab, int nwg, int ks, int cx, int cout, int cout_real, int cin_real, float* gw,
+                            int I_total, int i_off, int o_mul, int o_add, float* gb, int accumulate, hipStream_t st);
+int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out, int N, int H, int W, int C,
+                        long long flow_nstride, hipStream_t st);
+int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
+                        long long flow_nstride, hipStream_t st);
+int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, long long n, hipStream_t st);
+int vsr_launch_planar_to_pm(int dtype, const float* in, void* out, int N, int Cin, int H, int W, int C, hipStream_t st);
+int vsr_launch_pm_to_planar(int dtype, const void* in, float* out, int N, int Cout, int H, int W, int C, hipStream_t st);
+int vsr_launch_resize_norm(const float* in, float* out, const float* mean, const float* std, int F, int h, int w, int hu,
+                           int wu, hipStream_t st);
+int vsr_launch_avgpool2(const float* in, float* out, long long planes, int h, int w, hipStream_t st);
+int vsr_launch_spynet_prepare(int dtype, const float* frames, const float* flow_prev, float* flow_up, void* x16, int n,
+                              int t, int P, int pair_mode, int h, int w, int level0, hipStream_t st);
+int vsr_launch_flow_out(const float* in, float* out, int P, int hu, int wu, int h, int w, hipStream_t st);
+int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
+                            int I_total, int i_off, int o_mul, int o_add, int mode, hipStream_t st);
+int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps,
+                                hipStream_t st);
+
+#define VSR_WGRAD_NWG 512   // persistent wgrad workgroups: 2 per CU x 256 CUs

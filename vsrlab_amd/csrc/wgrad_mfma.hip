@@ -1,0 +1,337 @@
+// Weight / bias gradients of the convolutions on the BasicVSR path, on the matrix cores.
+//
+// What autograd's convolution_backward computes for the reference's nn.Conv2d layers
+// (635 calls per step), restated as one split-K GEMM per layer:
+//     dW[tap][cout][cin] = sum over pixels p of  dY[p][cout] * X[p + tap][cin]
+//   M = cout, N = cin, K = pixels.  Both operands are pixel-major ([pixel][channel]), i.e.
+//   K-strided, so the fragments are fetched from LDS with the CDNA4 transposing read
+//   ds_read_b64_tr_b16 (bf16) -- or plain ds_read_b32 for the exact-fp32 build.
+// A persistent 256-thread workgroup walks 8x32-pixel tiles of all frames ("segments") of the clip,
+// keeps its slice of dW in MFMA accumulators the whole time (wave = one (cout-block, cin-block),
+// all taps), and writes ONE fp32 partial slab at the end; wgrad_reduce sums the slabs into the
+// OIHW fp32 gradient.  Batching the t frames of a clip into one launch makes the slab traffic
+// (gridDim x 147 KB) small against the activations streamed (t x 132 MB for a 540p trunk conv).
+// The bias gradient rides along: column sums of dY accumulated while staging dY.
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 32, TH = 8, NTHREADS = 256;
+
+template <typename T> struct WElt;
+template <> struct WElt<bf16_t> { static constexpr int CHB = 16; typedef uint4 chunk_t; };
+struct wchunk32_t { uint4 a, b; };
+template <> struct WElt<float> { static constexpr int CHB = 32; typedef wchunk32_t chunk_t; };
+
+template <typename T> __device__ __forceinline__ typename WElt<T>::chunk_t wzero();
+template <> __device__ __forceinline__ uint4 wzero<bf16_t>() { return make_uint4(0, 0, 0, 0); }
+template <> __device__ __forceinline__ wchunk32_t wzero<float>() { wchunk32_t z; z.a = make_uint4(0, 0, 0, 0); z.b = z.a; return z; }
+
+__device__ __forceinline__ uint4 wchunk3(float a, float b, float c, bf16_t*) {
+    union { bf16_t h[8]; uint4 u; } t; t.u = make_uint4(0, 0, 0, 0);
+    t.h[0] = (bf16_t)a; t.h[1] = (bf16_t)b; t.h[2] = (bf16_t)c; return t.u;
+}
+__device__ __forceinline__ wchunk32_t wchunk3(float a, float b, float c, float*) {
+    wchunk32_t t; t.a = make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), 0); t.b = make_uint4(0, 0, 0, 0); return t;
+}
+__device__ __forceinline__ void chunk_sum(const uint4& v, float* s) {
+    union { uint4 u; bf16_t h[8]; } t; t.u = v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += (float)t.h[j];
+}
+__device__ __forceinline__ void chunk_sum(const wchunk32_t& v, float* s) {
+    s[0] += __uint_as_float(v.a.x); s[1] += __uint_as_float(v.a.y); s[2] += __uint_as_float(v.a.z); s[3] += __uint_as_float(v.a.w);
+    s[4] += __uint_as_float(v.b.x); s[5] += __uint_as_float(v.b.y); s[6] += __uint_as_float(v.b.z); s[7] += __uint_as_float(v.b.w);
+}
+
+// LDS chunk swizzle for the transposing reads: with 128-byte pixel rows (CP = 8) rows q and q+2 of a
+// 4-row tr block would share banks; flipping chunk bit 2 on every other pixel pair separates them.
+template <int CP> __device__ __forceinline__ int wswz(int pix, int c) {
+    return CP == 8 ? (c ^ (((pix >> 1) & 1) << 2)) : c;
+}
+
+// byte address of channel `ch` (multiple of 4 for tr reads) of pixel `pix`
+template <typename T, int CP> __device__ __forceinline__ int lds_addr(int pix, int ch) {
+    constexpr int CHB = WElt<T>::CHB;
+    return (pix * CP + wswz<CP>(pix, ch >> 3)) * CHB + (ch & 7) * (int)sizeof(T);
+}
+
+__device__ __forceinline__ s16x4_t tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
+// KS: kernel size; CX/COUT: LDS channel counts of X / dY (multiples of 16); *PLANAR: operand is a
+// planar fp32 3-channel image (LR frames, SR cotangent) padded to 16 channels on the way into LDS.
+template <typename T, int KS, int CX, bool XPLANAR, int COUT, bool DYPLANAR>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr int PAD = KS / 2, KK = KS * KS;
+    constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, NPIXX = THH * TWH, NPIXY = TH * TW;
+    constexpr int CPX = CX / 8, CPY = COUT / 8;
+    constexpr int CHB = WElt<T>::CHB;
+    constexpr int NCB = COUT >= 32 ? COUT / 32 : 1;
+    constexpr int NIB = CX >= 32 ? CX / 32 : 1;
+    constexpr int NT = NCB * NIB;                 // (cout-block, cin-block) pairs: 1, 2 or 4
+    constexpr int TAPSPLIT = 4 / NT;              // waves sharing one pair split the taps
+    constexpr int NTAP = (KK + TAPSPLIT - 1) / TAPSPLIT;
+    constexpr int COUTP = NCB * 32, CXP = NIB * 32;
+    constexpr int XBYTES = NPIXX * CPX * CHB;
+    typedef typename WElt<T>::chunk_t chunk_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lx = smem;
+    char* ly = smem + XBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int cb = wave % NCB, ib = (wave / NCB) % NIB, tap0 = wave / NT;
+
+    f32x16_t acc[NTAP];
+#pragma unroll
+    for (int i = 0; i < NTAP; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+    const int tiles_per_img = a.ntiles_x * a.ntiles_y;
+    const int ntiles = a.N * tiles_per_img;
+
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int n = tile / tiles_per_img;
+            const int tr = tile - n * tiles_per_img;
+            const int ty0 = (tr / a.ntiles_x) * TH, tx0 = (tr % a.ntiles_x) * TW;
+            __syncthreads();   // previous tile fully consumed
+            // ---- stage X (haloed) ----
+            if (XPLANAR) {
+                const float* base = reinterpret_cast<const float*>(a.x[seg]) + (long long)n * a.x_nstride;
+                const long long plane = (long long)a.Hx * a.Wx;
+                for (int p = tid; p < NPIXX; p += NTHREADS) {
+                    const int ty = p / TWH, tx = p - ty * TWH;
+                    const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
+                    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                    if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
+                        const long long o = (long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox);
+                        c0 = base[o]; c1 = base[o + plane]; c2 = base[o + 2 * plane];
+                    }
+                    *reinterpret_cast<chunk_t*>(lx + (p * 2 + 0) * CHB) = wchunk3(c0, c1, c2, (T*)nullptr);
+                    *reinterpret_cast<chunk_t*>(lx + (p * 2 + 1) * CHB) = wzero<T>();
+                }
+            } else {
+                const T* base = reinterpret_cast<const T*>(a.x[seg]) + (long long)n * a.x_nstride;
+                for (int idx = tid; idx < NPIXX * CPX; idx += NTHREADS) {
+                    const int p = idx / CPX, c = idx - p * CPX;
+                    const int ty = p / TWH, tx = p - ty * TWH;
+                    const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
+                    chunk_t v = wzero<T>();
+                    if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
+                        const long long o = ((long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox)) * CX + c * 8;
+                        v = *reinterpret_cast<const chunk_t*>(base + o);
+                    }
+                    *reinterpret_cast<chunk_t*>(lx + (p * CPX + wswz<CPX>(p, c)) * CHB) = v;
+                }
+            }
+            // ---- stage dY (no halo) + bias partial sums ----
+            if (DYPLANAR) {
+                const float* base = reinterpret_cast<const float*>(a.dy[seg]) + (long long)n * a.dy_nstride;
+                const long long plane = (long long)a.Hy * a.Wy;
+                for (int p = tid; p < NPIXY; p += NTHREADS) {
+                    const int ty = p / TW, tx = p - ty * TW;
+                    const int vy = ty0 + ty, vx = tx0 + tx;
+                    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                    if (vy < a.H && vx < a.W) {
+                        const long long o = (long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox);
+                        c0 = base[o]; c1 = base[o + plane]; c2 = base[o + 2 * plane];
+                    }
+                    bsum[0] += c0; bsum[1] += c1; bsum[2] += c2;
+                    *reinterpret_cast<chunk_t*>(ly + (p * 2 + 0) * CHB) = wchunk3(c0, c1, c2, (T*)nullptr);
+                    *reinterpret_cast<chunk_t*>(ly + (p * 2 + 1) * CHB) = wzero<T>();
+                }
+            } else {
+                const T* base = reinterpret_cast<const T*>(a.dy[seg]) + (long long)n * a.dy_nstride;
+                for (int idx = tid; idx < NPIXY * CPY; idx += NTHREADS) {   // NTHREADS % CPY == 0: chunk id is fixed per thread
+                    const int p = idx / CPY, c = idx - p * CPY;
+                    const int ty = p / TW, tx = p - ty * TW;
+                    const int vy = ty0 + ty, vx = tx0 + tx;
+                    chunk_t v = wzero<T>();
+                    if (vy < a.H && vx < a.W) {
+                        const long long o = ((long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox)) * COUT + c * 8;
+                        v = *reinterpret_cast<const chunk_t*>(base + o);
+                    }
+                    chunk_sum(v, bsum);
+                    *reinterpret_cast<chunk_t*>(ly + (p * CPY + wswz<CPY>(p, c)) * CHB) = v;
+                }
+            }
+            __syncthreads();
+
+            // ---- K loop: 8 rows x 2 half-rows of 16 pixels ----
+            for (int row = 0; row < TH; ++row) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int xk = half * 16;
+                    if constexpr (sizeof(T) == 2) {
+                        const int g2 = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+                        // channels 16..31 of a 16-channel operand do not exist: duplicate the low group
+                        const int chy = cb * 32 + (COUT >= 32 ? 16 * g2 : 0) + p4;
+                        const int chx = ib * 32 + (CX >= 32 ? 16 * g2 : 0) + p4;
+                        const int py = row * TW + xk + 8 * h + q;
+                        const s16x4_t a0 = tr_read(ly + lds_addr<T, CPY>(py, chy));
+                        const s16x4_t a1 = tr_read(ly + lds_addr<T, CPY>(py + 4, chy));
+                        bf16x8_t af;
+                        { union { s16x4_t s[2]; bf16x8_t b; } u; u.s[0] = a0; u.s[1] = a1; af = u.b; }
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) {
+                            const int tap = tap0 + i * TAPSPLIT;
+                            if (tap < KK) {
+                                const int ky = tap / KS, kx = tap - ky * KS;
+                                const int px = (row + ky) * TWH + xk + kx + 8 * h + q;
+                                const s16x4_t b0 = tr_read(lx + lds_addr<T, CPX>(px, chx));
+                                const s16x4_t b1 = tr_read(lx + lds_addr<T, CPX>(px + 4, chx));
+                                union { s16x4_t s[2]; bf16x8_t b; } u; u.s[0] = b0; u.s[1] = b1;
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, u.b, acc[i], 0, 0, 0);
+                            }
+                        }
+                    } else {
+                        const int chy = cb * 32 + (COUT >= 32 ? l31 : (l31 & 15));
+                        const int chx = ib * 32 + (CX >= 32 ? l31 : (l31 & 15));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int py = row * TW + xk + 2 * j + h;
+                            const float av = *reinterpret_cast<const float*>(ly + lds_addr<T, CPY>(py, chy));
+#pragma unroll
+                            for (int i = 0; i < NTAP; ++i) {
+                                const int tap = tap0 + i * TAPSPLIT;
+                                if (tap < KK) {
+                                    const int ky = tap / KS, kx = tap - ky * KS;
+                                    const int px = (row + ky) * TWH + xk + kx + 2 * j + h;
+                                    const float bv = *reinterpret_cast<const float*>(lx + lds_addr<T, CPX>(px, chx));
+                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- write this workgroup's partial slab: [tap][COUTP][CXP] then [COUTP] bias sums ----
+    float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < NTAP; ++i) {
+        const int tap = tap0 + i * TAPSPLIT;
+        if (tap < KK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[((long long)tap * COUTP + co) * CXP + ib * 32 + l31] = acc[i][r];
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);       // [NTHREADS][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < COUTP) {
+        float s = 0.f;
+        if (DYPLANAR) {
+            if (tid < 3) for (int t = 0; t < NTHREADS; ++t) s += red[t * 8 + tid];
+        } else if (tid < COUT) {
+            const int c = tid >> 3, j = tid & 7;       // thread t staged chunk (t % CPY)
+            for (int t = c; t < NTHREADS; t += CPY) s += red[t * 8 + j];
+        }
+        slab[(long long)KK * COUTP * CXP + tid] = s;
+    }
+}
+
+// Sum the partial slabs and scatter into the reference's OIHW fp32 gradient tensors.
+//   gw[(co*o_mul + o_add)][i_off + ci][ky][kx] (+)= sum_wg slab[wg][tap][co][ci]
+//   gb[co*o_mul + o_add]                        (+)= sum_wg slab[wg][bias tail][co]      (if gb && add_bias)
+__global__ void wgrad_reduce_kernel(const float* slab, int nwg, int slab_stride, int KK, int COUTP, int CXP,
+                                    int cout_real, int cin_real, float* gw, int I_total, int i_off, int o_mul, int o_add,
+                                    float* gb, int accumulate) {
+    const int total = KK * cout_real * cin_real;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int ci = idx % cin_real;
+        const int co = (idx / cin_real) % cout_real;
+        const int tap = idx / (cin_real * cout_real);
+        const float* p = slab + ((long long)tap * COUTP + co) * CXP + ci;
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += p[(long long)w * slab_stride];
+        float* d = gw + ((long long)(co * o_mul + o_add) * I_total + i_off + ci) * KK + tap;
+        *d = accumulate ? *d + s : s;
+    } else if (gb && idx < total + cout_real) {
+        const int co = idx - total;
+        const float* p = slab + (long long)KK * COUTP * CXP + co;
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += p[(long long)w * slab_stride];
+        float* d = gb + co * o_mul + o_add;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+template <typename T, int KS, int CX, bool XP, int COUT, bool DP>
+int launch_wgrad_inst(const WgradArgs& a0, int nwg, hipStream_t st) {
+    constexpr int TWH = TW + KS - 1, THH = TH + KS - 1;
+    constexpr int CHB = WElt<T>::CHB;
+    constexpr int LDS_T = THH * TWH * (CX / 8) * CHB + TH * TW * (COUT / 8) * CHB;
+    constexpr int LDS = LDS_T > NTHREADS * 8 * 4 ? LDS_T : NTHREADS * 8 * 4;
+    static_assert(LDS <= 160 * 1024, "wgrad tiles do not fit LDS");
+    auto kern = wgrad_kernel<T, KS, CX, XP, COUT, DP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    WgradArgs a = a0;
+    a.ntiles_x = cdiv(a.W, TW);
+    a.ntiles_y = cdiv(a.H, TH);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), LDS, st, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+}  // namespace
+
+#define VSR_WGRAD_SHAPES(X)           \
+    X(3, 64, false, 64, false)        /* trunk / upsample / conv_last.0 */ \
+    X(3, 16, true, 64, false)         /* stem, LR-frame part (conv.py:97) ; cleaner stem */ \
+    X(3, 64, false, 16, true)         /* conv_last.2 (dY = planar SR cotangent) */ \
+    X(1, 64, false, 64, false)        /* point_conv halves */
+
+// slab layout helper shared with the engine
+void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride) {
+    const int ncb = cout >= 32 ? cout / 32 : 1, nib = cx >= 32 ? cx / 32 : 1;
+    *coutp = ncb * 32;
+    *cxp = nib * 32;
+    *stride = ks * ks * (*coutp) * (*cxp) + (*coutp);
+}
+
+int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar,
+                     const WgradArgs& a, int nwg, hipStream_t st) {
+    if (a.nseg < 1 || a.nseg > VSR_WG_MAXSEG || nwg < 1) return VSR_ERR_BADARG;
+#define X(KS, CX, XP, COUT, DP)                                                                        \
+    if (ks == KS && cx == CX && (x_planar != 0) == XP && cout == COUT && (dy_planar != 0) == DP) {    \
+        if (dtype == VSR_BF16) return launch_wgrad_inst<bf16_t, KS, CX, XP, COUT, DP>(a, nwg, st);    \
+        if (dtype == VSR_F32) return launch_wgrad_inst<float, KS, CX, XP, COUT, DP>(a, nwg, st);      \
+        return VSR_ERR_BADARG;                                                                        \
+    }
+    VSR_WGRAD_SHAPES(X)
+#undef X
+    return VSR_ERR_UNSUPPORTED;
+}
+
+int vsr_launch_wgrad_reduce(const float* slab, int nwg, int ks, int cx, int cout, int cout_real, int cin_real,
+                            float* gw, int I_total, int i_off, int o_mul, int o_add, float* gb, int accumulate,
+                            hipStream_t st) {
+    int coutp, cxp, stride;
+    vsr_wgrad_slab_dims(ks, cx, cout, &coutp, &cxp, &stride);
+    const int total = ks * ks * cout_real * cin_real + (gb ? cout_real : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, slab, nwg, stride, ks * ks,
+                       coutp, cxp, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, accumulate);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}

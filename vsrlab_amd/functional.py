@@ -1,0 +1,357 @@
+"""torch-facing wrappers over the C ABI: PyTorch supplies device memory, the current HIP stream
+and autograd bookkeeping; every FLOP runs in libvsrlab_hip.so.
+
+There is deliberately no CPU / eager fallback: a tensor that is not on a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import weakref
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BasicVSRDesc, DT_BF16, DT_F32
+
+_DT = {"fp32": DT_F32, "float32": DT_F32, "f32": DT_F32, "bf16": DT_BF16, "bfloat16": DT_BF16}
+_TORCH_DT = {DT_F32: torch.float32, DT_BF16: torch.bfloat16}
+
+
+def resolve_dtype(compute_dtype: Optional[str] = None) -> int:
+    """Internal activation dtype: explicit argument > $VSRLAB_AMD_DTYPE > bf16 under autocast > fp32.
+
+    (The reference runs its forward under ``torch.cuda.amp.autocast()``, train.py:93; the
+    MI355X build maps that to bf16 storage / fp32 accumulate.)"""
+    name = compute_dtype or os.environ.get("VSRLAB_AMD_DTYPE")
+    if name is None:
+        name = "bf16" if torch.is_autocast_enabled() else "fp32"
+    if name not in _DT:
+        raise ValueError(f"unknown compute dtype {name!r}; use 'fp32' or 'bf16'")
+    return _DT[name]
+
+
+def _require_gpu(*tensors: torch.Tensor) -> None:
+    for x in tensors:
+        if not x.is_cuda:
+            raise RuntimeError("vsrlab_amd runs on MI355X only: got a CPU tensor and there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure)")
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(x: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if x is None else x.data_ptr())
+
+
+def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, x in enumerate(tensors):
+        arr[i] = 0 if x is None else x.data_ptr()
+    return arr
+
+
+def _f32c(x: torch.Tensor) -> torch.Tensor:
+    return x.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------- #
+# layout converters (reference planar fp32 <-> library pixel-major)
+# --------------------------------------------------------------------------------------------- #
+def to_pixel_major(x: torch.Tensor, dtype: int, channels: Optional[int] = None) -> torch.Tensor:
+    """(N,C,H,W) fp32 planar -> (N,H,W,Cp) pixel-major in the library's element type."""
+    _require_gpu(x)
+    n, c, h, w = x.shape
+    cp = channels or ((c + 15) // 16) * 16
+    out = torch.empty((n, h, w, cp), dtype=_TORCH_DT[dtype], device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.vsr_planar_to_pm(dtype, _ptr(_f32c(x)), _ptr(out), n, c, h, w, cp, _stream()), "planar_to_pm")
+    return out
+
+
+def from_pixel_major(x: torch.Tensor, channels: Optional[int] = None) -> torch.Tensor:
+    """(N,H,W,Cp) pixel-major -> (N,C,H,W) fp32 planar."""
+    _require_gpu(x)
+    n, h, w, cp = x.shape
+    c = channels or cp
+    dtype = DT_BF16 if x.dtype == torch.bfloat16 else DT_F32
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.vsr_pm_to_planar(dtype, _ptr(x.contiguous()), _ptr(out), n, c, h, w, cp, _stream()), "pm_to_planar")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- #
+# flow_warp  (reference: vsr/models/RealBasicVSR/modules/spynet.py:95-106)
+# --------------------------------------------------------------------------------------------- #
+class _FlowWarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow_planar, dtype):
+        n, c, h, w = x.shape
+        lib = _lib.load()
+        xin = to_pixel_major(x, dtype)
+        cp = xin.shape[-1]
+        out = torch.empty_like(xin)
+        flow_planar = _f32c(flow_planar)
+        _lib.check(lib.vsr_flow_warp_fwd(dtype, _ptr(xin), _ptr(flow_planar), _ptr(out), n, h, w, cp, _stream()), "flow_warp_fwd")
+        ctx.save_for_backward(flow_planar)
+        ctx.meta = (dtype, c, cp)
+        return from_pixel_major(out, c)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (flow_planar,) = ctx.saved_tensors
+        dtype, c, cp = ctx.meta
+        n, _, h, w = gout.shape
+        lib = _lib.load()
+        g = to_pixel_major(gout, dtype, cp)
+        acc = torch.zeros((n, h, w, cp), dtype=torch.float32, device=gout.device)
+        _lib.check(lib.vsr_flow_warp_bwd(dtype, _ptr(g), _ptr(flow_planar), _ptr(acc), n, h, w, cp, _stream()), "flow_warp_bwd")
+        return from_pixel_major(acc, c), None, None
+
+
+def flow_warp(x: torch.Tensor, flow: torch.Tensor, interpolation: str = "bilinear", padding_mode: str = "zeros",
+              align_corners: bool = True, compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """Drop-in for the reference ``flow_warp(x, flow)``: ``flow`` is channels-last (N,H,W,2),
+    [...,0] = horizontal displacement in pixels.  Differentiable w.r.t. ``x``."""
+    if interpolation != "bilinear" or padding_mode != "zeros" or not align_corners:
+        raise NotImplementedError("HIP flow_warp implements the BasicVSR propagation case: bilinear, zeros padding, "
+                                  "align_corners=True (border padding is fused inside the SPyNet kernels)")
+    _require_gpu(x, flow)
+    if flow.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("gradient w.r.t. the flow (train_flow=True) is not on the HIP path yet")
+    return _FlowWarpFn.apply(x, flow.permute(0, 3, 1, 2), resolve_dtype(compute_dtype))
+
+
+# --------------------------------------------------------------------------------------------- #
+# conv3x3 64->64 pieces (reference: core/modules/conv.py:82-92) -- per-op entry points
+# --------------------------------------------------------------------------------------------- #
+def conv3x3_c64(x_pm: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+                res_pm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _require_gpu(x_pm, weight)
+    n, h, w, c = x_pm.shape
+    assert c == 64 and tuple(weight.shape) == (64, 64, 3, 3)
+    dtype = DT_BF16 if x_pm.dtype == torch.bfloat16 else DT_F32
+    lib = _lib.load()
+    wpack = torch.empty(9 * 64 * 64, dtype=x_pm.dtype, device=x_pm.device)
+    y = torch.empty_like(x_pm)
+    _lib.check(lib.vsr_conv3x3_c64_fwd(dtype, _ptr(x_pm), _ptr(_f32c(weight)), _ptr(None if bias is None else _f32c(bias)),
+                                       _ptr(wpack), _ptr(y), _ptr(res_pm), act, n, h, w, _stream()), "conv3x3_c64_fwd")
+    return y
+
+
+def conv3x3_c64_dgrad(dy_pm: torch.Tensor, weight: torch.Tensor, res_pm: Optional[torch.Tensor] = None,
+                      aux_pm: Optional[torch.Tensor] = None, mask_mode: int = 0) -> torch.Tensor:
+    _require_gpu(dy_pm, weight)
+    n, h, w, c = dy_pm.shape
+    dtype = DT_BF16 if dy_pm.dtype == torch.bfloat16 else DT_F32
+    lib = _lib.load()
+    wpack = torch.empty(9 * 64 * 64, dtype=dy_pm.dtype, device=dy_pm.device)
+    dx = torch.empty_like(dy_pm)
+    _lib.check(lib.vsr_conv3x3_c64_dgrad(dtype, _ptr(dy_pm), _ptr(_f32c(weight)), _ptr(wpack), _ptr(dx), _ptr(res_pm),
+                                         _ptr(aux_pm), mask_mode, n, h, w, _stream()), "conv3x3_c64_dgrad")
+    return dx
+
+
+def conv3x3_c64_wgrad(x_pm: torch.Tensor, dy_pm: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _require_gpu(x_pm, dy_pm)
+    n, h, w, c = x_pm.shape
+    dtype = DT_BF16 if x_pm.dtype == torch.bfloat16 else DT_F32
+    lib = _lib.load()
+    slab = torch.empty(lib.vsr_conv3x3_c64_wgrad_slab_floats(), dtype=torch.float32, device=x_pm.device)
+    gw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x_pm.device)
+    gb = torch.empty((64,), dtype=torch.float32, device=x_pm.device)
+    _lib.check(lib.vsr_conv3x3_c64_wgrad(dtype, _ptr(x_pm), _ptr(dy_pm), _ptr(gw), _ptr(gb), _ptr(slab), n, h, w, _stream()),
+               "conv3x3_c64_wgrad")
+    return gw, gb
+
+
+class _ResidualConvFn(torch.autograd.Function):
+    """x + conv2(relu(conv1(x))) with its full backward, channels = 64 (conv.py:89-92)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, dtype):
+        xp = to_pixel_major(x, dtype)
+        a = conv3x3_c64(xp, w1, b1, act=1)
+        y = conv3x3_c64(a, w2, b2, act=0, res_pm=xp)
+        ctx.save_for_backward(xp, a, w1, w2)
+        return from_pixel_major(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, a, w1, w2 = ctx.saved_tensors
+        dtype = DT_BF16 if xp.dtype == torch.bfloat16 else DT_F32
+        g = to_pixel_major(gy, dtype)
+        ga = conv3x3_c64_dgrad(g, w2, aux_pm=a, mask_mode=1)
+        gx = conv3x3_c64_dgrad(ga, w1, res_pm=g)
+        gw2, gb2 = conv3x3_c64_wgrad(a, g)
+        gw1, gb1 = conv3x3_c64_wgrad(xp, ga)
+        return from_pixel_major(gx), gw1, gb1, gw2, gb2, None
+
+
+def residual_conv(x, w1, b1, w2, b2, compute_dtype: Optional[str] = None):
+    _require_gpu(x)
+    if x.shape[1] != 64:
+        raise NotImplementedError("the HIP ResidualConv is built for 64 channels (the reference default)")
+    return _ResidualConvFn.apply(x, w1, b1, w2, b2, resolve_dtype(compute_dtype))
+
+
+# --------------------------------------------------------------------------------------------- #
+# SPyNet forward (reference: vsr/models/RealBasicVSR/modules/spynet.py:69-93)
+# --------------------------------------------------------------------------------------------- #
+def spynet_flow(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.Tensor,
+                compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """``params``: the 62 Spynet tensors in state_dict order (60 conv tensors, mean, std)."""
+    _require_gpu(ref, supp)
+    if len(params) != 62:
+        raise ValueError("expected the 62 tensors of Spynet.state_dict()")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        raise NotImplementedError("SPyNet backward (train_flow=True) is not on the HIP path yet; freeze it or use no_grad")
+    dtype = resolve_dtype(compute_dtype)
+    n, _, h, w = ref.shape
+    lib = _lib.load()
+    ps = [_f32c(p) for p in params]
+    ws = torch.empty(lib.vsr_spynet_workspace_bytes(n, h, w, dtype), dtype=torch.uint8, device=ref.device)
+    flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=ref.device)
+    _lib.check(lib.vsr_spynet_forward(n, h, w, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(ref)), _ptr(_f32c(supp)), _ptr(flow),
+                                      _ptr(ws), ws.numel(), _stream()), "spynet_forward")
+    return flow
+
+
+# --------------------------------------------------------------------------------------------- #
+# whole BasicVSR path (reference: modules/basicvsr.py:39-83 + autograd)
+# --------------------------------------------------------------------------------------------- #
+class Workspace:
+    """One arena per in-flight forward.  A forward that needs a backward keeps its arena until
+    that backward has run (or its graph was dropped)."""
+
+    def __init__(self, nbytes: int, device):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.owner = None      # weakref to the autograd ctx that still needs the saved activations
+
+    def free(self) -> bool:
+        return self.owner is None or self.owner() is None
+
+
+class WorkspacePool:
+    def __init__(self):
+        self._pool = {}
+
+    def acquire(self, key, nbytes: int, device) -> Workspace:
+        for ws in self._pool.setdefault(key, []):
+            if ws.free():
+                ws.owner = None
+                return ws
+        ws = Workspace(nbytes, device)
+        self._pool[key].append(ws)
+        return ws
+
+    def clear(self):
+        self._pool.clear()
+
+
+class _CtxToken:
+    """weakref-able handle tying a workspace to the lifetime of an autograd graph node."""
+
+
+class _BasicVSRFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lrs, desc_tuple, pool, n_trainable, *params):
+        n, t, h, w, mid, rb, up, dtype = desc_tuple
+        desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
+        lib = _lib.load()
+        need_bwd = bool(n_trainable) and torch.is_grad_enabled() and any(p.requires_grad for p in params[:n_trainable])
+        nbytes = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(desc), int(need_bwd))
+        if nbytes == 0:
+            raise RuntimeError(f"vsrlab_amd: unsupported BasicVSR configuration for the HIP path: {desc_tuple}")
+        ws = pool.acquire((desc_tuple, need_bwd, lrs.device.index), nbytes, lrs.device)
+        lr32 = _f32c(lrs)
+        ps = [_f32c(p) for p in params]
+        sr = torch.empty((n, t, 3, up * h, up * w), dtype=torch.float32, device=lrs.device)
+        _lib.check(lib.vsr_basicvsr_forward(ctypes.byref(desc), _ptr_array(ps), len(ps), _ptr(lr32), _ptr(sr), _ptr(ws.buf),
+                                            ws.buf.numel(), int(need_bwd), _stream()), "basicvsr_forward")
+        if need_bwd:
+            token = _CtxToken()
+            ctx.token = token
+            ws.owner = weakref.ref(token)
+        ctx.ws = ws
+        ctx.desc_tuple = desc_tuple
+        ctx.n_trainable = n_trainable
+        ctx.need_bwd = need_bwd
+        ctx.lr32 = lr32
+        ctx.ps = ps
+        return sr
+
+    @staticmethod
+    def backward(ctx, dsr):
+        if not ctx.need_bwd:
+            raise RuntimeError("vsrlab_amd: backward through a forward that ran without need_backward")
+        n, t, h, w, mid, rb, up, dtype = ctx.desc_tuple
+        desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
+        lib = _lib.load()
+        ps = ctx.ps
+        grads: List[Optional[torch.Tensor]] = [
+            torch.zeros_like(p) if (k < ctx.n_trainable and ctx.needs_input_grad[4 + k]) else None for k, p in enumerate(ps)]
+        want_all = [g if g is not None else (torch.zeros_like(p) if k < ctx.n_trainable else None)
+                    for k, (g, p) in enumerate(zip(grads, ps))]   # engine produces weight+bias grads together
+        _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(want_all), len(ps), _ptr(ctx.lr32),
+                                             _ptr(_f32c(dsr)), _ptr(ctx.ws.buf), ctx.ws.buf.numel(), _stream()),
+                   "basicvsr_backward")
+        ctx.ws.owner = None
+        ctx.token = None
+        return (None, None, None, None) + tuple(grads)
+
+
+def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_trainable: int, mid_channels: int,
+                     res_blocks: int, upscale: int, pool: WorkspacePool, compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """sr = BasicVSR(lrs) on the HIP engine.  ``params`` in state_dict order; the first
+    ``n_trainable`` are the non-SPyNet tensors (SPyNet is frozen: basicvsr.py:25-28)."""
+    _require_gpu(lrs)
+    if lrs.dim() != 5 or lrs.shape[2] != 3:
+        raise ValueError("lrs must be (n,t,3,h,w)")
+    if lrs.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("gradient w.r.t. the LR clip (RealBasicVSR pre-clean stack) is not on the HIP path yet")
+    n, t, _, h, w = lrs.shape
+    desc_tuple = (n, t, h, w, mid_channels, res_blocks, upscale, resolve_dtype(compute_dtype))
+    return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, *params)
+
+
+def basicvsr_flows(lrs_shape, mid_channels, res_blocks, upscale, ws: Workspace, dtype: int, device):
+    n, t, _, h, w = lrs_shape
+    desc = BasicVSRDesc(n, t, h, w, mid_channels, res_blocks, upscale, dtype)
+    ff = torch.empty((n, t - 1, 2, h, w), dtype=torch.float32, device=device)
+    fb = torch.empty_like(ff)
+    lib = _lib.load()
+    _lib.check(lib.vsr_basicvsr_get_flows(ctypes.byref(desc), _ptr(ws.buf), _ptr(ff), _ptr(fb), _stream()), "get_flows")
+    return ff, fb
+
+
+# --------------------------------------------------------------------------------------------- #
+# Charbonnier loss (reference: core/losses.py:10-18), fused value + gradient
+# --------------------------------------------------------------------------------------------- #
+class _CharbonnierFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, eps):
+        lib = _lib.load()
+        x32, y32 = _f32c(x), _f32c(y)
+        dx = torch.empty_like(x32)
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        _lib.check(lib.vsr_charbonnier_fwd_bwd(_ptr(x32), _ptr(y32), _ptr(dx), _ptr(loss), x32.numel(), float(eps), _stream()),
+                   "charbonnier")
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None, None
+
+
+def charbonnier_loss(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
+    _require_gpu(x, y)
+    if y.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("HIP Charbonnier differentiates w.r.t. its first argument only")
+    return _CharbonnierFn.apply(x, y, eps)
