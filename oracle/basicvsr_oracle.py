@@ -35,6 +35,63 @@ SPYNET_LEVELS = 6                    # spynet.py:29
 
 
 # --------------------------------------------------------------------------- #
+# optional emulation of the perf build's storage precision
+# --------------------------------------------------------------------------- #
+# The HIP perf build stores every activation and activation-gradient in bf16 and feeds the
+# matrix cores bf16 weights, accumulating in fp32.  ``emulate_bf16()`` makes this oracle round at
+# exactly those points (same algorithm, fp32 arithmetic, bf16 storage), which gives the bf16 build a
+# TIGHT checker instead of a loose "bf16 is noisy" tolerance.  Default: no rounding (the reference).
+class _RoundBoth(torch.autograd.Function):          # stored activation: value and its gradient are bf16
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundGrad(torch.autograd.Function):          # fp32 tensor whose cotangent is staged as bf16
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+_EMULATE_BF16 = False
+
+
+class emulate_bf16:
+    def __enter__(self):
+        global _EMULATE_BF16
+        self._prev = _EMULATE_BF16
+        _EMULATE_BF16 = True
+
+    def __exit__(self, *exc):
+        global _EMULATE_BF16
+        _EMULATE_BF16 = self._prev
+
+
+def _q(x: Tensor) -> Tensor:        # stored activation
+    return _RoundBoth.apply(x) if _EMULATE_BF16 else x
+
+
+def _wq(w: Tensor) -> Tensor:       # weight as fed to the MFMA (its gradient stays fp32)
+    return w + (w.to(torch.bfloat16).to(w.dtype) - w).detach() if _EMULATE_BF16 else w
+
+
+def _iq(x: Tensor) -> Tensor:       # fp32 boundary tensor staged as bf16 (LR frame into the stem conv)
+    return x.to(torch.bfloat16).to(x.dtype) if _EMULATE_BF16 else x
+
+
+def _gq(x: Tensor) -> Tensor:       # fp32 output whose cotangent is staged as bf16 (SR frame)
+    return _RoundGrad.apply(x) if _EMULATE_BF16 else x
+
+
+# --------------------------------------------------------------------------- #
 # deterministic, init-order-independent parameters
 # --------------------------------------------------------------------------- #
 def basicvsr_param_shapes(mid_channels: int = 64, res_blocks: int = 30,
@@ -148,7 +205,9 @@ def _spynet_level(sd: Mapping[str, Tensor], prefix: str, lvl: int, x: Tensor) ->
     """5 x (conv7x7 pad 3 + ReLU); the ReLU also follows the LAST conv (spynet.py:16-18)."""
     for j in range(len(SPYNET_CHANNELS)):
         k = f"{prefix}basic_module.{lvl}.basic_module.{j}.conv.0."
-        x = F.relu(F.conv2d(x, sd[k + "weight"], sd[k + "bias"], stride=1, padding=3))
+        x = F.relu(F.conv2d(x, _wq(sd[k + "weight"]), sd[k + "bias"], stride=1, padding=3))
+        if j < len(SPYNET_CHANNELS) - 1:
+            x = _q(x)          # the last layer's 2 channels stay fp32 (planar flow)
     return x
 
 
@@ -172,7 +231,7 @@ def spynet_compute_flow(sd: Mapping[str, Tensor], ref: Tensor, supp: Tensor,
         else:                                                      # spynet.py:54
             flow_up = F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
         warped = flow_warp(supps[lvl], flow_up, padding_mode="border")  # spynet.py:58-60
-        res = _spynet_level(sd, prefix, lvl, torch.cat([refs[lvl], warped, flow_up], 1))
+        res = _spynet_level(sd, prefix, lvl, _q(torch.cat([refs[lvl], warped, flow_up], 1)))
         flow = flow_up + res                                       # spynet.py:65
     return flow
 
@@ -196,14 +255,14 @@ def spynet_forward(sd: Mapping[str, Tensor], ref: Tensor, supp: Tensor, prefix: 
 # --------------------------------------------------------------------------- #
 def residual_conv(sd: Mapping[str, Tensor], prefix: str, x: Tensor) -> Tensor:
     """x + conv2(relu(conv1(x)))  (core/modules/conv.py:82-92)."""
-    y = F.relu(F.conv2d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding=1))
-    y = F.conv2d(y, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding=1)
-    return x + y
+    y = _q(F.relu(F.conv2d(x, _wq(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"], padding=1)))
+    y = F.conv2d(y, _wq(sd[prefix + "conv2.weight"]), sd[prefix + "conv2.bias"], padding=1)
+    return _q(x + y)
 
 
 def residual_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor, blocks: int) -> Tensor:
     """conv3x3 + LeakyReLU(0.1), then ``blocks`` ResidualConv (core/modules/conv.py:94-103)."""
-    x = F.leaky_relu(F.conv2d(x, sd[prefix + "conv.0.weight"], sd[prefix + "conv.0.bias"], padding=1), 0.1)
+    x = _q(F.leaky_relu(F.conv2d(x, _wq(sd[prefix + "conv.0.weight"]), sd[prefix + "conv.0.bias"], padding=1), 0.1))
     for i in range(blocks):
         x = residual_conv(sd, f"{prefix}res_block.{i}.", x)
     return x
@@ -211,8 +270,8 @@ def residual_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor, blocks: int
 
 def pixel_shuffle_pack(sd: Mapping[str, Tensor], prefix: str, x: Tensor) -> Tensor:
     """conv3x3 C->4C then PixelShuffle(2), no activation (core/modules/upsampling.py:4-12)."""
-    y = F.conv2d(x, sd[prefix + "upconv.weight"], sd[prefix + "upconv.bias"], padding=1)
-    return F.pixel_shuffle(y, 2)
+    y = F.conv2d(x, _wq(sd[prefix + "upconv.weight"]), sd[prefix + "upconv.bias"], padding=1)
+    return _q(F.pixel_shuffle(y, 2))
 
 
 def count_res_blocks(sd: Mapping[str, Tensor], prefix: str = "") -> int:
@@ -258,24 +317,24 @@ def basicvsr_forward(sd: Mapping[str, Tensor], lrs: Tensor, prefix: str = "",
     feat = lrs.new_zeros(n, mid, h, w)
     for i in range(t - 1, -1, -1):                                  # basicvsr.py:48-60
         if i < t - 1:
-            feat = flow_warp(feat, flows_backward[:, i])
-        feat = residual_block(sd, prefix + "backward_resblocks.", torch.cat([lrs[:, i], feat], 1), rb)
+            feat = _q(flow_warp(feat, flows_backward[:, i]))
+        feat = residual_block(sd, prefix + "backward_resblocks.", torch.cat([_iq(lrs[:, i]), feat], 1), rb)
         feats_bwd[i] = feat
 
     outs = []
     feat = torch.zeros_like(feat)
     for i in range(t):                                              # basicvsr.py:64-82
         if i > 0:
-            feat = flow_warp(feat, flows_forward[:, i - 1])
-        feat = residual_block(sd, prefix + "forward_resblocks.", torch.cat([lrs[:, i], feat], 1), rb)
-        o = F.conv2d(torch.cat([feats_bwd[i], feat], 1), sd[prefix + "point_conv.0.weight"],
+            feat = _q(flow_warp(feat, flows_forward[:, i - 1]))
+        feat = residual_block(sd, prefix + "forward_resblocks.", torch.cat([_iq(lrs[:, i]), feat], 1), rb)
+        o = F.conv2d(torch.cat([feats_bwd[i], feat], 1), _wq(sd[prefix + "point_conv.0.weight"]),
                      sd[prefix + "point_conv.0.bias"])
-        o = F.leaky_relu(o, 0.1)
+        o = _q(F.leaky_relu(o, 0.1))
         for k in range(n_up):
             o = pixel_shuffle_pack(sd, f"{prefix}upsample.{k}.", o)
-        o = F.leaky_relu(F.conv2d(o, sd[prefix + "conv_last.0.weight"], sd[prefix + "conv_last.0.bias"],
-                                  padding=1), 0.1)
-        o = F.conv2d(o, sd[prefix + "conv_last.2.weight"], sd[prefix + "conv_last.2.bias"], padding=1)
+        o = _q(F.leaky_relu(F.conv2d(o, _wq(sd[prefix + "conv_last.0.weight"]), sd[prefix + "conv_last.0.bias"],
+                                     padding=1), 0.1))
+        o = _gq(F.conv2d(o, _wq(sd[prefix + "conv_last.2.weight"]), sd[prefix + "conv_last.2.bias"], padding=1))
         base = F.interpolate(lrs[:, i], scale_factor=2 ** n_up, mode="bilinear", align_corners=False)
         outs.append(o + base)
     return torch.stack(outs, 1)

@@ -18,6 +18,7 @@
 // Epilogue (fused, in accumulator layout): bias, ReLU/LeakyReLU(0.1), residual add,
 // activation-gradient mask, pixel-shuffle placement, or planar fp32 store with residual /
 // bilinear x4 skip.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -372,10 +373,37 @@ int launch_inst(const ConvArgs& a, hipStream_t st) {
     X(7, 1, 32, 32, false, 32, EPI_NHWC)    \
     X(7, 1, 16, 16, false, 32, EPI_PLANAR)  /* SPyNet 16->2 (+ReLU) + flow_up residual          */
 
+int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st);
+
+// VSRLAB_AMD_GENERIC_CONV=1 routes the hot shape through the generic tiled kernel (A/B testing only).
+static bool vsr_force_generic_conv() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VSRLAB_AMD_GENERIC_CONV");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 // Host dispatcher (C++ linkage, used by the engine and by the C-ABI per-op entry points).
 int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar, int cout_t, int epi,
                     const ConvArgs& a, hipStream_t st) {
     if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.nz < 1 || a.nz > VSR_MAX_Z) return VSR_ERR_BADARG;
+    // the hot shape has its own persistent, weights-resident kernel (conv3x3_persist.hip)
+    if (dtype == VSR_BF16 && ks == 3 && nsrc == 1 && ca == 64 && cb == 64 && !last_planar && cout_t == 64 && epi == EPI_NHWC &&
+        a.in_step == 1 && a.src_oy[0] == 0 && a.src_ox[0] == 0 && a.Hs == a.H && a.Ws == a.W && a.CD == 64 && a.cout_real == 64 &&
+        a.src[0] != nullptr && !vsr_force_generic_conv()) {
+        static int num_cus = 0;
+        if (num_cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            HIP_CHECK_RET(hipGetDevice(&dev));
+            HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+            num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int ps = vsr_launch_conv3x3_c64_persist(a, num_cus, st);
+        if (ps != VSR_ERR_UNSUPPORTED) return ps;
+    }
 #define X(KS, NSRC, CA, CB, LP, COUT, EPI)                                                             \
     if (ks == KS && nsrc == NSRC && ca == CA && cb == CB && (last_planar != 0) == LP && cout_t == COUT && epi == EPI) { \
         if (dtype == VSR_BF16) return launch_inst<bf16_t, KS, NSRC, CA, CB, LP, COUT, EPI>(a, st);    \

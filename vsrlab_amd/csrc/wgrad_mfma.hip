@@ -252,23 +252,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
 __global__ void wgrad_reduce_kernel(const float* slab, int nwg, int slab_stride, int KK, int COUTP, int CXP,
                                     int cout_real, int cin_real, float* gw, int I_total, int i_off, int o_mul, int o_add,
                                     float* gb, int accumulate) {
+    // block = 64 consecutive output elements x 4 slab groups: 64-lane rows of every slab are read
+    // coalesced, 4 groups keep enough loads in flight; fixed summation order => bitwise reproducible.
+    __shared__ float part[4][64];
     const int total = KK * cout_real * cin_real;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
+    const float* p = nullptr;
+    float* d = nullptr;
     if (idx < total) {
         const int ci = idx % cin_real;
         const int co = (idx / cin_real) % cout_real;
         const int tap = idx / (cin_real * cout_real);
-        const float* p = slab + ((long long)tap * COUTP + co) * CXP + ci;
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += p[(long long)w * slab_stride];
-        float* d = gw + ((long long)(co * o_mul + o_add) * I_total + i_off + ci) * KK + tap;
-        *d = accumulate ? *d + s : s;
+        p = slab + ((long long)tap * COUTP + co) * CXP + ci;
+        d = gw + ((long long)(co * o_mul + o_add) * I_total + i_off + ci) * KK + tap;
     } else if (gb && idx < total + cout_real) {
         const int co = idx - total;
-        const float* p = slab + (long long)KK * COUTP * CXP + co;
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += p[(long long)w * slab_stride];
-        float* d = gb + co * o_mul + o_add;
+        p = slab + (long long)KK * COUTP * CXP + co;
+        d = gb + co * o_mul + o_add;
+    }
+    float s = 0.f;
+    if (p) {
+        int w = grp;
+        for (; w + 12 < nwg; w += 16) {
+            const float v0 = p[(long long)w * slab_stride], v1 = p[(long long)(w + 4) * slab_stride];
+            const float v2 = p[(long long)(w + 8) * slab_stride], v3 = p[(long long)(w + 12) * slab_stride];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; w < nwg; w += 4) s += p[(long long)w * slab_stride];
+    }
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && d) {
+        s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
         *d = accumulate ? *d + s : s;
     }
 }
@@ -330,7 +346,7 @@ int vsr_launch_wgrad_reduce(const float* slab, int nwg, int ks, int cx, int cout
     int coutp, cxp, stride;
     vsr_wgrad_slab_dims(ks, cx, cout, &coutp, &cxp, &stride);
     const int total = ks * ks * cout_real * cin_real + (gb ? cout_real : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, slab, nwg, stride, ks * ks,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, nwg, stride, ks * ks,
                        coutp, cxp, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, accumulate);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;

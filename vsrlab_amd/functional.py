@@ -259,11 +259,10 @@ class _CtxToken:
 
 class _BasicVSRFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lrs, desc_tuple, pool, n_trainable, *params):
+    def forward(ctx, lrs, desc_tuple, pool, n_trainable, need_bwd, *params):
         n, t, h, w, mid, rb, up, dtype = desc_tuple
         desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
         lib = _lib.load()
-        need_bwd = bool(n_trainable) and torch.is_grad_enabled() and any(p.requires_grad for p in params[:n_trainable])
         nbytes = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(desc), int(need_bwd))
         if nbytes == 0:
             raise RuntimeError(f"vsrlab_amd: unsupported BasicVSR configuration for the HIP path: {desc_tuple}")
@@ -294,7 +293,7 @@ class _BasicVSRFn(torch.autograd.Function):
         lib = _lib.load()
         ps = ctx.ps
         grads: List[Optional[torch.Tensor]] = [
-            torch.zeros_like(p) if (k < ctx.n_trainable and ctx.needs_input_grad[4 + k]) else None for k, p in enumerate(ps)]
+            torch.zeros_like(p) if (k < ctx.n_trainable and ctx.needs_input_grad[5 + k]) else None for k, p in enumerate(ps)]
         want_all = [g if g is not None else (torch.zeros_like(p) if k < ctx.n_trainable else None)
                     for k, (g, p) in enumerate(zip(grads, ps))]   # engine produces weight+bias grads together
         _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(want_all), len(ps), _ptr(ctx.lr32),
@@ -302,7 +301,7 @@ class _BasicVSRFn(torch.autograd.Function):
                    "basicvsr_backward")
         ctx.ws.owner = None
         ctx.token = None
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_trainable: int, mid_channels: int,
@@ -316,7 +315,9 @@ def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_traina
         raise NotImplementedError("gradient w.r.t. the LR clip (RealBasicVSR pre-clean stack) is not on the HIP path yet")
     n, t, _, h, w = lrs.shape
     desc_tuple = (n, t, h, w, mid_channels, res_blocks, upscale, resolve_dtype(compute_dtype))
-    return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, *params)
+    # grad mode is off inside Function.forward, so decide here whether activations must be retained
+    need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params[:n_trainable])
+    return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, need_bwd, *params)
 
 
 def basicvsr_flows(lrs_shape, mid_channels, res_blocks, upscale, ws: Workspace, dtype: int, device):
