@@ -1,0 +1,33 @@
+"""Diagnostic: per-phase cycle shares of the persistent conv kernel (needs `make -C vsrlab_amd/csrc STAMPS=1`)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(ROOT, "vsrlab_amd", "lib", "libvsrlab_hip_stamps.so"))
+P = ctypes.c_void_p
+h, w = 540, 960
+dev = torch.device("cuda:0")
+x = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
+r = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
+y = torch.empty_like(x)
+wgt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
+b = torch.zeros(64, device=dev)
+wpack = torch.empty(9 * 64 * 64, dtype=torch.bfloat16, device=dev)
+st = P(torch.cuda.current_stream().cuda_stream)
+for res, act, name in ((None, 1, "bias+relu"), (r, 0, "bias+res")):
+    for _ in range(3):
+        lib.vsr_conv3x3_c64_fwd(1, P(x.data_ptr()), P(wgt.data_ptr()), P(b.data_ptr()), P(wpack.data_ptr()), P(y.data_ptr()),
+                                P(res.data_ptr() if res is not None else 0), act, 1, h, w, st)
+    torch.cuda.synchronize()
+    out = np.zeros(256 * 8 * 8, dtype=np.uint64)
+    assert lib.vsr_debug_read_stamps(out.ctypes.data_as(P)) == 0
+    s = out.reshape(256, 8, 8).astype(np.float64)
+    names = ["(unused)", "stage tile (HBM->LDS)", "group barrier 1", "K loop", "group barrier 2", "epilogue", "group barrier 3"]
+    tot = s[:, :, :7].sum(-1).mean()
+    print(f"[{name}] mean cycles per wave (s_memtime ticks = 100 MHz?): total {tot:.0f}")
+    for k, nm in enumerate(names):
+        print(f"   {nm:26s} mean {s[:, :, k].mean():10.0f}  min {s[:, :, k].min():10.0f} max {s[:, :, k].max():10.0f}  share {s[:, :, k].mean() / tot:6.1%}")
