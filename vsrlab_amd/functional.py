@@ -26,7 +26,7 @@ def resolve_dtype(compute_dtype: Optional[str] = None) -> int:
     MI355X build maps that to bf16 storage / fp32 accumulate.)"""
     name = compute_dtype or os.environ.get("VSRLAB_AMD_DTYPE")
     if name is None:
-        name = "bf16" if torch.is_autocast_enabled() else "fp32"
+        name = "bf16" if torch.is_autocast_enabled("cuda") else "fp32"
     if name not in _DT:
         raise ValueError(f"unknown compute dtype {name!r}; use 'fp32' or 'bf16'")
     return _DT[name]
