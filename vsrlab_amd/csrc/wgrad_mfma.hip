@@ -12,6 +12,7 @@
 // OIHW fp32 gradient.  Batching the t frames of a clip into one launch makes the slab traffic
 // (gridDim x 147 KB) small against the activations streamed (t x 132 MB for a 540p trunk conv).
 // The bias gradient rides along: column sums of dY accumulated while staging dY.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -310,6 +311,235 @@ int launch_wgrad_inst(const WgradArgs& a0, int nwg, hipStream_t st) {
     return VSR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16, 3x3, 64 -> 64: the shape that carries ~all weight-gradient FLOPs.  Same maths as wgrad_kernel,
+// restructured around the memory system (this GEMM streams X and dY exactly once: at MFMA speed it would
+// need > 8 TB/s, so it is HBM-bound and everything is about keeping loads in flight):
+//   * ONE 512-thread workgroup per CU; both operand tiles are DOUBLE-BUFFERED in LDS (2 x 74.5 KiB) and
+//     filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), issued one whole tile
+//     ahead of the MFMAs.  The swizzle for the transposing reads is applied on the per-lane SOURCE address;
+//     out-of-image pixels read a 16-byte zero word, so border tiles need no special path.
+//   * 8 waves = (cout-block, cin-block, row-half): each wave keeps 9 taps x 32x32 in 144 accumulator
+//     registers and covers 4 of the tile's 8 rows; the two row-halves write separate slabs.
+// ---------------------------------------------------------------------------------------------------
+__device__ uint4 g_zero_chunk[2];
+
+constexpr int DX_PIX = (TH + 2) * (TW + 2);          // 340 haloed pixels
+constexpr int DXB = DX_PIX * 128;                    // 43,520
+constexpr int DYB = TH * TW * 128;                   // 32,768
+constexpr int DSET = DXB + DYB;                      // 76,288 per buffer set
+constexpr int DX_PIECES = (DX_PIX * 8 + 63) / 64;    // 43 (the last one half full)
+constexpr int DY_PIECES = TH * TW * 8 / 64;          // 32
+constexpr int DNT = 512;
+
+__global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int cb = wave & 1, ib = (wave >> 1) & 1, kh = wave >> 2;
+    constexpr int TWH = TW + 2;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+    const int tiles_per_img = a.ntiles_x * a.ntiles_y;
+    const int per_seg = a.N * tiles_per_img;
+    const int total = a.nseg * per_seg;
+    const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
+
+    // DMA pieces of this wave: piece = wave + 8 i (43 X pieces, then 32 dY pieces).  rel[i] = this lane's source
+    // byte offset relative to the tile's origin pixel (valid for interior tiles: ~20 VALU per tile instead of
+    // ~40 per piece, which made the first DMA version VALU-bound: 6.8 VALU per MFMA measured).
+    constexpr int NPIECE = (DX_PIECES + DY_PIECES + 7) / 8;       // 10
+    int rel[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int piece = wave + 8 * i;
+        if (piece < DX_PIECES) {
+            const int idx = piece * 64 + lane;
+            const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
+            const int ty = p / TWH, tx = p - ty * TWH;
+            rel[i] = (((ty - 1) * a.x_step * a.Wx + (tx - 1) * a.x_step) * 64 + c * 8) * 2;
+        } else {
+            const int idx = (piece - DX_PIECES) * 64 + lane;
+            const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
+            rel[i] = (((p >> 5) * a.dy_step * a.Wy + (p & 31) * a.dy_step) * 64 + c * 8) * 2;
+        }
+    }
+    auto issue = [&](int T, int s) {
+        const int seg = T / per_seg;
+        const int r0 = T - seg * per_seg;
+        const int n = r0 / tiles_per_img;
+        const int r1 = r0 - n * tiles_per_img;
+        const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
+        const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
+        const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
+        char* lxs = smem + s * DSET;
+        const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;      // wave-uniform
+        if (interior) {
+            const char* xo = xb + ((long long)(ty0 * a.x_step + a.x_oy) * a.Wx + (tx0 * a.x_step + a.x_ox)) * 128;
+            const char* yo = yb + ((long long)(ty0 * a.dy_step + a.dy_oy) * a.Wy + (tx0 * a.dy_step + a.dy_ox)) * 128;
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) {
+                const int piece = wave + 8 * i;
+                if (piece < DX_PIECES) {
+                    if (piece * 64 + lane < DX_PIX * 8)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xo + rel[i]),
+                                                         (__attribute__((address_space(3))) void*)(lxs + piece * 1024), 16, 0, 0);
+                } else if (piece < DX_PIECES + DY_PIECES) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(yo + rel[i]),
+                                                     (__attribute__((address_space(3))) void*)(lxs + DXB + (piece - DX_PIECES) * 1024), 16, 0, 0);
+                }
+            }
+            return;
+        }
+        for (int piece = wave; piece < DX_PIECES + DY_PIECES; piece += 8) {     // border tile: per-lane bounds, zero source
+            const char* src = zsrc;
+            if (piece < DX_PIECES) {
+                const int idx = piece * 64 + lane;
+                const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
+                const int ty = p / TWH, tx = p - ty * TWH;
+                const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+                if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W)
+                    src = xb + (((long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox)) * 64 + c * 8) * 2;
+                if (idx < DX_PIX * 8)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lxs + piece * 1024), 16, 0, 0);
+            } else {
+                const int q = piece - DX_PIECES;
+                const int idx = q * 64 + lane;
+                const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
+                const int vy = ty0 + (p >> 5), vx = tx0 + (p & 31);
+                if (vy < a.H && vx < a.W)
+                    src = yb + (((long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox)) * 64 + c * 8) * 2;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lxs + DXB + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    int cur = 0;
+    int T = blockIdx.x;
+    if (T < total) issue(T, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int g2 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+    const int chy = cb * 32 + 16 * g2 + p4, chx = ib * 32 + 16 * g2 + p4;
+    const int ybase = (8 * h + q4) * 128 + (((chy >> 3) ^ (((q4 >> 1) & 1) << 2)) << 4) + (chy & 7) * 2;
+    int xbase[2][3];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+            xbase[par][kx] = (8 * h + q4) * 128 + (((chx >> 3) ^ ((par ^ (((kx + q4) >> 1) & 1)) << 2)) << 4) + (chx & 7) * 2;
+    for (; T < total; T += gridDim.x) {
+        const int next = T + gridDim.x;
+        if (next < total) issue(next, cur ^ 1);               // a whole tile ahead of the MFMAs
+        const char* lx = smem + cur * DSET;
+        const char* ly = lx + DXB;
+        // bias partial sums: this thread's channel chunk (tid & 7) of 4 pixels of the dY tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = (tid >> 3) + 64 * i;
+            chunk_sum(*reinterpret_cast<const uint4*>(ly + (p * 8 + ((tid & 7) ^ (((p >> 1) & 1) << 2))) * 16), bsum);
+        }
+        // K loop.  All LDS addresses are lane-constant base + wave-uniform row offset + immediate: the swizzle
+        // bit of pixel pix is ((pix >> 1) & 1); with 34- and 32-pixel rows it reduces to
+        //   X : (row parity) ^ (((kx + q4) >> 1) & 1)        dY : ((q4 >> 1) & 1)
+        // (per-read address arithmetic made an earlier version VALU-bound: ~150 VALU per 9 MFMAs).
+#pragma unroll 1
+        for (int r2 = 0; r2 < 2; ++r2) {         // 144 accumulators: keep the body small
+            // 12 groups g = (k-step ks = rr*2 + half, ky): 3 MFMAs each.  The B fragments of group g+2 and the
+            // A fragment of the next k-step are requested before group g's MFMAs issue, so an LDS round trip
+            // (~130 cycles) is covered by 6 MFMAs instead of being waited for in front of every MFMA.
+            typedef union { s16x4_t s[2]; bf16x8_t b; } frag_u;
+            frag_u A[2], B[3][3];
+            const char* lyr = ly + ybase + (kh * 4 + r2 * 2) * (TW * 128);
+            const char* lxr = lx + (kh * 4 + r2 * 2) * (TWH * 128);
+            auto loadA = [&](int ks, frag_u& f) {
+                const char* pa = lyr + (ks >> 1) * (TW * 128) + (ks & 1) * 2048;
+                f.s[0] = tr_read(pa);
+                f.s[1] = tr_read(pa + 512);
+            };
+            auto loadB = [&](int g, frag_u* f) {
+                const int ks = g / 3, ky = g - 3 * ks, rr = ks >> 1, half = ks & 1;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const char* pb = lxr + xbase[(rr + ky) & 1][kx] + ((rr + ky) * TWH + half * 16 + kx) * 128;
+                    f[kx].s[0] = tr_read(pb);
+                    f[kx].s[1] = tr_read(pb + 512);
+                }
+            };
+            loadA(0, A[0]);
+            loadB(0, B[0]);
+            loadB(1, B[1]);
+            // Written as a macro so that every group index is a literal: sched_group_barrier takes constants.
+            // The barrier pair pins the interleave "this group's LDS requests, then its 3 MFMAs" (hipcc
+            // otherwise sinks the reads back in front of their consumers).
+#define WG_GROUP(g)                                                                                                        \
+            {                                                                                                              \
+                constexpr int ks = (g) / 3, ky = (g) - 3 * ks;                                                             \
+                if (ky == 0 && ks + 1 < 4) loadA(ks + 1, A[(ks + 1) & 1]);                                                 \
+                if ((g) + 2 < 12) loadB((g) + 2, B[((g) + 2) % 3]);                                                        \
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                           \
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1].b, B[(g) % 3][kx].b, acc[ky * 3 + kx], 0, 0, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, ((g) + 2 < 12 ? 6 : 0) + ((ky == 0 && ks + 1 < 4) ? 2 : 0), 0); \
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                         \
+            }
+            WG_GROUP(0) WG_GROUP(1) WG_GROUP(2) WG_GROUP(3) WG_GROUP(4) WG_GROUP(5)
+            WG_GROUP(6) WG_GROUP(7) WG_GROUP(8) WG_GROUP(9) WG_GROUP(10) WG_GROUP(11)
+#undef WG_GROUP
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile has landed (this wave's pieces)
+        __syncthreads();                                       // ... everybody's; and `cur` is free again
+        cur ^= 1;
+    }
+
+    // ---- partial slabs: one per (workgroup, row-half): [tap][64][64] then [64] bias sums ----
+    float* slab = a.slab + (long long)(blockIdx.x * 2 + kh) * a.slab_stride;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            slab[((long long)tap * 64 + co) * 64 + ib * 32 + l31] = acc[tap][r];
+        }
+    float* red = reinterpret_cast<float*>(smem);               // [512][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        const int c = tid >> 3, j = tid & 7;                   // thread t summed chunk (t & 7)
+        for (int t = c; t < DNT; t += 8) s += red[t * 8 + j];
+        a.slab[(long long)(blockIdx.x * 2) * a.slab_stride + 9 * 64 * 64 + tid] = s;
+        a.slab[(long long)(blockIdx.x * 2 + 1) * a.slab_stride + 9 * 64 * 64 + tid] = 0.f;
+    }
+}
+
+int launch_wgrad_dma(const WgradArgs& a0, int nslabs, hipStream_t st) {
+    constexpr int LDS = 2 * DSET;                              // 152,576
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_c64_dma_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    WgradArgs a = a0;
+    a.ntiles_x = cdiv(a.W, TW);
+    a.ntiles_y = cdiv(a.H, TH);
+    hipLaunchKernelGGL(wgrad3x3_c64_dma_kernel, dim3(nslabs / 2), dim3(DNT), LDS, st, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
 }  // namespace
 
 #define VSR_WGRAD_SHAPES(X)           \
@@ -329,6 +559,12 @@ void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* st
 int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar,
                      const WgradArgs& a, int nwg, hipStream_t st) {
     if (a.nseg < 1 || a.nseg > VSR_WG_MAXSEG || nwg < 1) return VSR_ERR_BADARG;
+    {   // hot shape: LDS-DMA double-buffered kernel (needs an even slab count: 2 row-halves per workgroup)
+        static int force_generic = -1;
+        if (force_generic < 0) { const char* e = getenv("VSRLAB_AMD_GENERIC_WGRAD"); force_generic = (e && e[0] == '1') ? 1 : 0; }
+        if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2 && nwg % 2 == 0)
+            return launch_wgrad_dma(a, nwg, st);
+    }
 #define X(KS, CX, XP, COUT, DP)                                                                        \
     if (ks == KS && cx == CX && (x_planar != 0) == XP && cout == COUT && (dy_planar != 0) == DP) {    \
         if (dtype == VSR_BF16) return launch_wgrad_inst<bf16_t, KS, CX, XP, COUT, DP>(a, nwg, st);    \
