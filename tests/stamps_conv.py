@@ -26,8 +26,8 @@ for res, act, name in ((None, 1, "bias+relu"), (r, 0, "bias+res")):
     out = np.zeros(256 * 8 * 8, dtype=np.uint64)
     assert lib.vsr_debug_read_stamps(out.ctypes.data_as(P)) == 0
     s = out.reshape(256, 8, 8).astype(np.float64)
-    names = ["(unused)", "stage tile (HBM->LDS)", "group barrier 1", "K loop", "group barrier 2", "epilogue", "group barrier 3"]
-    tot = s[:, :, :7].sum(-1).mean()
+    names = ["(unused)", "issue DMA + epilogue operand loads", "K loop", "barrier (tile consumed)", "epilogue", "wait next tile + barrier"]
+    tot = s[:, :4, :6].sum(-1).mean()
     print(f"[{name}] mean cycles per wave (s_memtime ticks = 100 MHz?): total {tot:.0f}")
     for k, nm in enumerate(names):
-        print(f"   {nm:26s} mean {s[:, :, k].mean():10.0f}  min {s[:, :, k].min():10.0f} max {s[:, :, k].max():10.0f}  share {s[:, :, k].mean() / tot:6.1%}")
+        print(f"   {nm:26s} mean {s[:, :4, k].mean():10.0f}  min {s[:, :4, k].min():10.0f} max {s[:, :4, k].max():10.0f}  share {s[:, :4, k].mean() / tot:6.1%}")

@@ -2,36 +2,41 @@
 //   core/modules/conv.py:85-86 (ResidualConv conv1/conv2), basicvsr.py:20 (conv_last.0),
 //   upsampling.py:7 (as 4 pixel-shuffle phases), and all their data gradients: > 70 % of the FLOPs.
 //
-// Persistent design for one MI355X CU (160 KiB LDS, 4 SIMDs):
-//   * ONE 512-thread workgroup per CU, grid = #CUs.  The packed weight tensor [9 taps][64 cout][64 cin]
-//     bf16 (72 KiB) is loaded into LDS once and shared by everybody.
-//   * the 8 waves form TWO independent groups of 4 waves (one wave of each group per SIMD).  Each
-//     group walks its own 8x32-pixel tiles with its own haloed 10x34-pixel LDS buffer (42.5 KiB) and
-//     synchronises only within the group (a 4-wave barrier on an LDS counter), so the two groups drift
-//     apart: while one group waits for HBM or runs its epilogue, the other one owns the matrix pipes.
-//   * no barrier inside the 144-MFMA K loop: A (weights) and B (pixels) fragments are plain
-//     ds_read_b128 at register base + immediate offset.  Both LDS images are XOR-swizzled on the
-//     16-byte chunk index (weights by cout row, pixels by x only, so a tap shift in y is a pure
-//     immediate offset) => conflict-free reads (SQ_LDS_BANK_CONFLICT = 0 measured).
-//   * epilogue: the accumulator layout (lane = pixel, registers = channels) would store 8-byte pieces
-//     into 32 different 128-byte lines per instruction (measured: as expensive as the K loop).  Each
-//     wave therefore transposes its rows through a private 8 KiB slot of its group's (now idle) tile
-//     buffer, fp32, and then reads residual / mask and writes the result as whole 128-byte pixel
-//     lines, 16 bytes per lane.  Fused: bias, ReLU / LeakyReLU(0.1), residual add, activation-gradient
-//     mask, pixel-shuffle placement; one rounding to bf16 at the very end.
+// At 540p one launch moves 133-200 MB for 38 GFLOP: 21-32 us at the 6.3 TB/s a CU-side stream reaches,
+// 15 us on the matrix cores -- the kernel is HBM-bound, and a CU needs ~75 KB in flight to cover ~3 us of
+// loaded HBM latency.  Design for one MI355X CU (160 KiB LDS, 4 SIMDs):
+//   * ONE 256-thread workgroup per CU (one wave per SIMD, up to 512 VGPRs each), grid = #CUs, persistent
+//     over 8x32-pixel tiles.  The packed weights [9 taps][64 cout][64 cin] bf16 (72 KiB) are loaded into LDS
+//     once and stay.
+//   * the haloed 10x34-pixel input tile is DOUBLE-BUFFERED in LDS (2 x 42.5 KiB) and filled by LDS-DMA
+//     (global_load_lds_dwordx4) one whole tile ahead; the residual / mask operands of the epilogue are
+//     requested into registers before the K loop.  Nothing the tile needs is waited for at first use.
+//   * K loop: 144 v_mfma_f32_32x32x16_bf16 per wave and tile, no barrier inside; A (weights) and B (pixels)
+//     fragments are ds_read_b128 at register base + immediate, requested two k-steps ahead of their MFMAs
+//     (explicit 3-deep ring, order pinned with sched_group_barrier: a lone wave per SIMD has nobody to hide
+//     an LDS round trip behind).  Both LDS images are XOR-swizzled on the 16-byte chunk (weights by cout
+//     row, pixels by x only => a ky shift is an immediate); the pixel swizzle is applied on the DMA's
+//     per-lane SOURCE address.  SQ_LDS_BANK_CONFLICT = 0 measured.
+//   * epilogue: the accumulator layout (lane = pixel, registers = channels) would store 8-byte pieces into
+//     32 different 128-byte lines per instruction (measured: as expensive as the K loop).  Each wave
+//     transposes its rows through a private 8 KiB fp32 slot of the tile buffer it has just finished with and
+//     writes whole 128-byte pixel lines, 16 bytes per lane.  Fused: bias, ReLU / LeakyReLU(0.1), residual
+//     add, activation-gradient mask, pixel-shuffle placement; one rounding to bf16 at the very end.
 #include "common.h"
 
 namespace {
 
-constexpr int PTW = 32, PTH = 8, PNT = 512, GNT = 256;
+constexpr int PTW = 32, PTH = 8, PNT = 256;
 constexpr int PTWH = PTW + 2, PTHH = PTH + 2, PNPIX = PTHH * PTWH;       // 34 x 10 = 340 haloed pixels
 constexpr int W_BYTES = 9 * 64 * 64 * 2;                                  // 73,728
-constexpr int IN_BYTES = PNPIX * 128;                                     // 43,520 per group (>= 4 waves x 8 KiB slots)
+constexpr int IN_BYTES = PNPIX * 128;                                     // 43,520 per buffer (>= 4 waves x 8 KiB slots)
 constexpr int BIAS_BYTES = 256;                                           // 64 fp32
-constexpr int CNT_BYTES = 64;                                             // group-barrier counters
-constexpr int P_LDS = W_BYTES + 2 * IN_BYTES + BIAS_BYTES + CNT_BYTES;    // 161,088 <= 163,840
+constexpr int P_LDS = W_BYTES + 2 * IN_BYTES + BIAS_BYTES;                // 161,024 <= 163,840
 constexpr int IN_CHUNKS = PNPIX * 8;                                      // 2,720 16-byte chunks
-constexpr int PRE = (IN_CHUNKS + GNT - 1) / GNT;                          // 11 chunks per thread
+constexpr int NPIECE_T = (IN_CHUNKS + 63) / 64;                           // 43 DMA pieces of 1 KiB (last half full)
+constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11 per wave
+
+__device__ uint4 g_conv_zero_chunk[2];
 
 template <int ACT> __device__ __forceinline__ float p_act(float v) {
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -72,75 +77,71 @@ __device__ __forceinline__ void unpack_bf8(const uint4& u, float* f) {
     for (int j = 0; j < 8; ++j) f[j] = (float)t.h[j];
 }
 
-// Barrier over the 4 waves of one group, on a monotonic LDS counter.  Every wave first drains its own
-// LDS queue (its reads have returned, its writes have landed: the LDS executes a wave's operations in
-// order), then arrives; all lanes poll the same word, so the loop is wave-uniform.  Global-memory
-// operations are deliberately NOT waited for: epilogue stores stay in flight across the barrier.
-__device__ __forceinline__ void group_barrier(unsigned* cnt, unsigned& target, int lane) {
-    target += 4;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-}
+#define GLDS16(src, dst)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 // Epilogue variants are compile-time: a runtime-selected epilogue serialises 16 load->use->store
 // chains per tile (measured: 14 us of a 71 us launch).
 template <int ACT, bool HAS_RES, int MASK>
-__global__ __launch_bounds__(PNT, 2) void conv3x3_c64_persist_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = wave >> 2, gw = wave & 3, gtid = tid & (GNT - 1);
     const int l31 = lane & 31, h = lane >> 5;
     char* lds_w = smem;
-    char* lds_in = smem + W_BYTES + grp * IN_BYTES;                      // this group's tile buffer
+    char* lds_t = smem + W_BYTES;                                         // two tile buffers
     float* lds_bias = reinterpret_cast<float*>(smem + W_BYTES + 2 * IN_BYTES);
-    unsigned* gcnt = reinterpret_cast<unsigned*>(smem + W_BYTES + 2 * IN_BYTES + BIAS_BYTES) + grp * 8;
 
     const int z = blockIdx.y;
     const int ntx = cdiv(a.W, PTW), nty = cdiv(a.H, PTH);
     const int total = a.N * ntx * nty;
     if (tid < 64) lds_bias[tid] = a.bias ? a.bias[(long long)z * a.bias_zstride + tid] : 0.f;
-    if (tid < 16) reinterpret_cast<unsigned*>(smem + W_BYTES + 2 * IN_BYTES + BIAS_BYTES)[tid] = 0u;
 
     // ---- weights of this z: global [tap][cout][cin] -> LDS, chunk c of row r at (r*8 + (c ^ ((r>>1)&7))) ----
     {
         const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.wpack) + (long long)z * a.w_zstride);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < 18; ++i) {
             const int idx = tid + i * PNT;                 // 4608 chunks
             const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;
             *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[idx];
         }
     }
-    __syncthreads();                                        // the only workgroup-wide barrier
-    unsigned btarget = 0;
 
-    const bf16_t* src = reinterpret_cast<const bf16_t*>(a.src[0]);
-    // stage one haloed tile: chunk idx = gtid + 256 i -> pixel p = idx>>3 (ty = p/34, tx = p%34), chunk c = idx&7
-    auto stage = [&](int tile) {
+    // ---- DMA pieces of this wave: piece = wave + 4 i.  LDS slot (pixel p, position q) of a piece receives
+    // global chunk q ^ ((tx>>1)&7) of pixel p; rel[i] = this lane's source byte offset from the tile origin ----
+    const char* src = reinterpret_cast<const char*>(a.src[0]);
+    const char* zsrc = reinterpret_cast<const char*>(g_conv_zero_chunk);
+    int rel[NPIECE_W];
+#pragma unroll
+    for (int i = 0; i < NPIECE_W; ++i) {
+        const int idx = (wave + 4 * i) * 64 + lane;
+        const int p = idx >> 3;
+        const int ty = p / PTWH, tx = p - ty * PTWH;
+        rel[i] = (((ty - 1) * a.W + (tx - 1)) * 64 + ((idx & 7) ^ ((tx >> 1) & 7)) * 8) * 2;
+    }
+    auto issue = [&](int tile, int buf) {
         int n, ty0, tx0;
         tile_coords(tile, ntx, nty, n, ty0, tx0);
-        const bf16_t* org = src + (long long)n * a.src_nstride[0] + ((long long)(ty0 - 1) * a.W + (tx0 - 1)) * 64;
-        uint4 pre[PRE];
-        const bool interior = ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W;   // wave-uniform
+        const char* org = src + ((long long)n * a.src_nstride[0] + ((long long)ty0 * a.W + tx0) * 64) * 2;
+        char* dstb = lds_t + buf * IN_BYTES;
+        if (ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W) {          // interior tile (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int idx = gtid + i * GNT;
-            const int p = idx >> 3, c = idx & 7;
-            const int ty = p / PTWH, tx = p - ty * PTWH;
-            const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < IN_CHUNKS && (interior || (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W)))
-                v = *reinterpret_cast<const uint4*>(org + (ty * a.W + tx) * 64 + c * 8);
-            pre[i] = v;
-        }
+            for (int i = 0; i < NPIECE_W; ++i) {
+                const int piece = wave + 4 * i;
+                if (piece < NPIECE_T && piece * 64 + lane < IN_CHUNKS) GLDS16(org + rel[i], dstb + piece * 1024);
+            }
+        } else {                                                                    // border: bounds per lane, zero source
 #pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int idx = gtid + i * GNT;
-            const int p = idx >> 3, c = idx & 7;
-            const int tx = p % PTWH;
-            if (idx < IN_CHUNKS) *reinterpret_cast<uint4*>(lds_in + (p * 8 + (c ^ ((tx >> 1) & 7))) * 16) = pre[i];
+            for (int i = 0; i < NPIECE_W; ++i) {
+                const int piece = wave + 4 * i;
+                const int idx = piece * 64 + lane;
+                const int p = idx >> 3;
+                const int ty = p / PTWH, tx = p - ty * PTWH;
+                const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+                const char* s = (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) ? org + rel[i] : zsrc;
+                if (piece < NPIECE_T && idx < IN_CHUNKS) GLDS16(s, dstb + piece * 1024);
+            }
         }
     };
 
@@ -158,22 +159,52 @@ __global__ __launch_bounds__(PNT, 2) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int tx = l31 + kx;
-            b_off[kx][ks] = ((gw * 2 * PTWH + tx) * 8 + ((2 * ks + h) ^ ((tx >> 1) & 7))) * 16;
+            b_off[kx][ks] = ((wave * 2 * PTWH + tx) * 8 + ((2 * ks + h) ^ ((tx >> 1) & 7))) * 16;
         }
-    // epilogue transposition slot of this wave: fp32 [32 pixels][64 channels], 16-byte chunk q of pixel
-    // px stored at chunk (q ^ (px & 15))
-    char* slot = lds_in + gw * 8192;
-    const int rpx = lane >> 3, rch = lane & 7;            // read-back role: pixel rpx + 8*it, channels 8*rch..8*rch+7
+    const int rpx = lane >> 3, rch = lane & 7;            // epilogue role: pixel rpx + 8*it, channels 8*rch..8*rch+7
 
 #ifdef VSR_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (int tile = blockIdx.x * 2 + grp; tile < total; tile += gridDim.x * 2) {
+    int cur = 0;
+    int tile = blockIdx.x;
+    if (tile < total) issue(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // weights, bias and the first tile are in LDS
+
+    float4 breg[2][4];                                    // this lane's 32 bias values (accumulator layout), for the whole launch
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) breg[cb][g] = *reinterpret_cast<const float4*>(lds_bias + cb * 32 + 8 * g + 4 * h);
+
+    for (; tile < total; tile += gridDim.x) {
         STAMP(t0);
-        stage(tile);
+        const int next = tile + gridDim.x;
+        if (next < total) issue(next, cur ^ 1);            // a whole tile ahead of the MFMAs
+        const char* lds_in = lds_t + cur * IN_BYTES;
+
+        // epilogue operands, requested now, used after the K loop
+        int n, ty0, tx0;
+        tile_coords(tile, ntx, nty, n, ty0, tx0);
+        long long off[2][4];
+        bool ok[2][4];
+        uint4 rr[2][4], mm[2][4];
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            const int vy = ty0 + wave * 2 + rw;
+            const int oy = vy * a.out_step + a.out_oy[z];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int vx = tx0 + rpx + 8 * it;
+                ok[rw][it] = vy < a.H && vx < a.W;
+                const int ox = vx * a.out_step + a.out_ox[z];
+                off[rw][it] = (long long)n * a.dst_nstride + ((long long)oy * a.Wd + ox) * 64 + rch * 8;
+                if (HAS_RES && ok[rw][it]) rr[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + off[rw][it]);
+                if (MASK != MASK_NONE && ok[rw][it]) mm[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + off[rw][it]);
+            }
+        }
         STAMP(t1);
-        group_barrier(gcnt, btarget, lane);                 // tile visible to the group
-        STAMP(t2);
 
         f32x16_t acc[2][2];
 #pragma unroll
@@ -183,39 +214,69 @@ __global__ __launch_bounds__(PNT, 2) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[cb][rw][i] = 0.f;
 
+        // ---- K loop: 36 steps s = (tap, ks) of 4 MFMAs.  The 4 fragment reads of step s+2 are issued before
+        // the MFMAs of step s, by hand: the reads are inline asm with a counted s_waitcnt (lgkmcnt(8) = "all
+        // but the 8 youngest LDS reads have returned" = step s is in registers), because hipcc's scheduler
+        // sinks builtin LDS reads back in front of their consumers (measured: ds_read x4, lgkmcnt(0), mfma x4).
+        // A lone wave per SIMD has nobody else to hide an LDS round trip behind.
+        bf16x8_t fa[3][2], fb[3][2];
+        unsigned bb[3][4];                                   // B base addresses of this tile's buffer
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8_t af[2], bf[2];
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) af[cb] = *reinterpret_cast<const bf16x8_t*>(lds_w + tap * 8192 + a_off[cb][ks]);
-#pragma unroll
-                for (int rw = 0; rw < 2; ++rw) bf[rw] = *reinterpret_cast<const bf16x8_t*>(lds_in + (rw + ky) * (PTWH * 128) + b_off[kx][ks]);
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int rw = 0; rw < 2; ++rw)
-                        acc[cb][rw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb], bf[rw], acc[cb][rw], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks) bb[kx][ks] = (unsigned)(W_BYTES + cur * IN_BYTES + b_off[kx][ks]);
+#define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define CV_LOAD(s, slot)                                                                                               \
+        {                                                                                                              \
+            constexpr int tap_ = (s) / 4, ks_ = (s) % 4, ky_ = tap_ / 3, kx_ = tap_ % 3;                               \
+            if (tap_ < 8) {                                                                                            \
+                DSR(fa[slot][0], (unsigned)a_off[0][ks_], tap_ < 8 ? tap_ * 8192 : 0);                                 \
+                DSR(fa[slot][1], (unsigned)a_off[1][ks_], tap_ < 8 ? tap_ * 8192 : 0);                                 \
+            } else {                                                                                                   \
+                DSR(fa[slot][0], (unsigned)a_off[0][ks_] + 8192u, 57344);                                              \
+                DSR(fa[slot][1], (unsigned)a_off[1][ks_] + 8192u, 57344);                                              \
+            }                                                                                                          \
+            DSR(fb[slot][0], bb[kx_][ks_], ky_ * (PTWH * 128));                                                        \
+            DSR(fb[slot][1], bb[kx_][ks_], (1 + ky_) * (PTWH * 128));                                                  \
         }
+#define CV_STEP(s)                                                                                                     \
+        {                                                                                                              \
+            if ((s) + 2 < 36) CV_LOAD((s) + 2, ((s) + 2) % 3)                                                          \
+            if ((s) + 2 < 36) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                       \
+            else if ((s) + 1 < 36) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                  \
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(s) % 3][0], fb[(s) % 3][0], acc[0][0], 0, 0, 0);   \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(s) % 3][0], fb[(s) % 3][1], acc[0][1], 0, 0, 0);   \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(s) % 3][1], fb[(s) % 3][0], acc[1][0], 0, 0, 0);   \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(s) % 3][1], fb[(s) % 3][1], acc[1][1], 0, 0, 0);   \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of ours is outstanding: the counts below are exact
+        __builtin_amdgcn_sched_barrier(0);
+        CV_LOAD(0, 0)
+        CV_LOAD(1, 1)
+        CV_STEP(0) CV_STEP(1) CV_STEP(2) CV_STEP(3) CV_STEP(4) CV_STEP(5) CV_STEP(6) CV_STEP(7) CV_STEP(8)
+        CV_STEP(9) CV_STEP(10) CV_STEP(11) CV_STEP(12) CV_STEP(13) CV_STEP(14) CV_STEP(15) CV_STEP(16) CV_STEP(17)
+        CV_STEP(18) CV_STEP(19) CV_STEP(20) CV_STEP(21) CV_STEP(22) CV_STEP(23) CV_STEP(24) CV_STEP(25) CV_STEP(26)
+        CV_STEP(27) CV_STEP(28) CV_STEP(29) CV_STEP(30) CV_STEP(31) CV_STEP(32) CV_STEP(33) CV_STEP(34) CV_STEP(35)
+#undef CV_STEP
+#undef CV_LOAD
+#undef DSR
+        STAMP(t2);
+        __syncthreads();                 // every wave has finished reading this tile: its buffer is free for the slots
         STAMP(t3);
-        group_barrier(gcnt, btarget, lane);                 // the group has finished reading the tile
-        STAMP(t4);
 
         // ---- epilogue ----
-        int n, ty0, tx0;
-        tile_coords(tile, ntx, nty, n, ty0, tx0);
+        char* slot = lds_t + cur * IN_BYTES + wave * 8192;   // fp32 [32 pixels][64 ch], chunk q of pixel px at q ^ (px & 15)
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
-            // (1) bias + activation in accumulator layout, fp32, into the wave's slot
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = cb * 32 + 8 * g + 4 * h;
-                    const float4 b = *reinterpret_cast<const float4*>(lds_bias + co);
+                    const float4 b = breg[cb][g];
                     float4 v;
                     v.x = p_act<ACT>(acc[cb][rw][4 * g + 0] + b.x); v.y = p_act<ACT>(acc[cb][rw][4 * g + 1] + b.y);
                     v.z = p_act<ACT>(acc[cb][rw][4 * g + 2] + b.z); v.w = p_act<ACT>(acc[cb][rw][4 * g + 3] + b.w);
@@ -223,38 +284,26 @@ __global__ __launch_bounds__(PNT, 2) void conv3x3_c64_persist_kernel(const ConvA
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // (2) read back pixel-major, finish in whole 128-byte lines: all loads first, then math + stores
-            const int vy = ty0 + gw * 2 + rw;
-            const int oy = vy * a.out_step + a.out_oy[z];
-            float4 lo[4], hi[4];
-            uint4 rr[4], mm[4];
-            long long off[4];
-            bool ok[4];
+            float4 lo[4], hi[4];                          // all 8 reads in flight together: one LDS round trip per row
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int px = rpx + 8 * it;
                 lo[it] = *reinterpret_cast<const float4*>(slot + px * 256 + (((2 * rch) ^ (px & 15)) << 4));
                 hi[it] = *reinterpret_cast<const float4*>(slot + px * 256 + (((2 * rch + 1) ^ (px & 15)) << 4));
-                const int vx = tx0 + px;
-                ok[it] = vy < a.H && vx < a.W;
-                const int ox = vx * a.out_step + a.out_ox[z];
-                off[it] = (long long)n * a.dst_nstride + ((long long)oy * a.Wd + ox) * 64 + rch * 8;
-                if (HAS_RES && ok[it]) rr[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + off[it]);
-                if (MASK != MASK_NONE && ok[it]) mm[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + off[it]);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                if (ok[it]) {
+                if (ok[rw][it]) {
                     float v[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
                     if (HAS_RES) {
                         float r[8];
-                        unpack_bf8(rr[it], r);
+                        unpack_bf8(rr[rw][it], r);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += r[j];
                     }
                     if (MASK != MASK_NONE) {
                         float m[8];
-                        unpack_bf8(mm[it], m);
+                        unpack_bf8(mm[rw][it], m);
                         constexpr float neg = MASK == MASK_LEAKY ? 0.1f : 0.f;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] *= (m[j] > 0.f ? 1.f : neg);
@@ -262,16 +311,18 @@ __global__ __launch_bounds__(PNT, 2) void conv3x3_c64_persist_kernel(const ConvA
                     union { uint4 q; bf16_t hh[8]; } pk;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pk.hh[j] = (bf16_t)v[j];
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.dst[z]) + off[it]) = pk.q;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.dst[z]) + off[rw][it]) = pk.q;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        STAMP(t4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (this wave's pieces)
+        __syncthreads();                                      // ... everybody's; the slots are no longer read
+        cur ^= 1;
         STAMP(t5);
-        group_barrier(gcnt, btarget, lane);                 // every wave of the group has left the tile buffer
-        STAMP(t6);
-        STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5); STAMP_ADD(6, t5, t6);
+        STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5);
     }
 #ifdef VSR_STAMPS
     if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
@@ -290,7 +341,7 @@ static int launch_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
     const int tiles = a.N * cdiv(a.W, PTW) * cdiv(a.H, PTH);
     int gx = num_cus / a.nz;
     if (gx < 1) gx = 1;
-    if (gx > (tiles + 1) / 2) gx = (tiles + 1) / 2;
+    if (gx > tiles) gx = tiles;
     hipLaunchKernelGGL(kern, dim3(gx, a.nz), dim3(PNT), P_LDS, st, a);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
@@ -312,7 +363,7 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     for (int z = 0; z < a.nz; ++z) { res = res || a.res[z]; aux = aux || a.aux[z]; }
     for (int z = 0; z < a.nz; ++z) if ((res && !a.res[z]) || (aux && !a.aux[z])) return VSR_ERR_UNSUPPORTED;
     const int mask = aux ? a.mask_mode : MASK_NONE;
-    if ((long long)(PTHH + 1) * a.W * 64 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;   // in-tile offsets are 32-bit
+    if ((long long)(PTHH + 1) * a.W * 128 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;   // in-tile byte offsets are 32-bit
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
     PERSIST_CASE(ACT_RELU, false, MASK_NONE)     // conv1 of a ResidualConv
     PERSIST_CASE(ACT_NONE, true, MASK_NONE)      // conv2 + skip ; dgrad(conv1) + dX
