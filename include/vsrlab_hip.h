@@ -100,7 +100,8 @@ int vsr_pm_to_planar(int dtype, const void* in_pm, float* out, int N, int Cout, 
                      void* stream);
 
 /* y = act(conv3x3(x, w) + b) [+ res]   64->64, stride 1, pad 1 (core/modules/conv.py:85-86).
- * w: fp32 OIHW (64,64,3,3) ; wpack: scratch of 9*64*64 elements of `dtype`;
+ * w: fp32 OIHW (64,64,3,3) ; wpack: scratch of 9*64*64 elements of `dtype`, filled from w by this call
+ * (w == NULL: wpack is taken as already packed by an earlier call -- lets a caller time the conv alone);
  * act: 0 none / 1 ReLU / 2 LeakyReLU(0.1); res_pm may be NULL.                               */
 int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float* b, void* wpack,
                         void* y_pm, const void* res_pm, int act, int N, int H, int W, void* stream);

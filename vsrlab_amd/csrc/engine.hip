@@ -659,7 +659,7 @@ static ConvArgs plain64(const void* x, const void* wpack, const float* b, void* 
 int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float* b, void* wpack, void* y_pm, const void* res_pm,
                         int act, int N, int H, int W, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    CK(vsr_launch_pack_weights(dtype, w, wpack, 9, C, C, C, C, C, 0, 1, 0, 0, st));
+    if (w) CK(vsr_launch_pack_weights(dtype, w, wpack, 9, C, C, C, C, C, 0, 1, 0, 0, st));   // w == NULL: wpack already packed
     ConvArgs a = plain64(x_pm, wpack, b, y_pm, N, H, W);
     a.act = act; a.res[0] = res_pm;
     return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
