@@ -162,6 +162,12 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             b_off[kx][ks] = ((wave * 2 * PTWH + tx) * 8 + ((2 * ks + h) ^ ((tx >> 1) & 7))) * 16;
         }
     const int rpx = lane >> 3, rch = lane & 7;            // epilogue role: pixel rpx + 8*it, channels 8*rch..8*rch+7
+    int loff[2][4];                                       // lane-constant part of the destination element offset
+#pragma unroll
+    for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            loff[rw][it] = (((wave * 2 + rw) * a.out_step) * a.Wd + (rpx + 8 * it) * a.out_step) * 64 + rch * 8;
 
 #ifdef VSR_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -187,21 +193,17 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         // epilogue operands, requested now, used after the K loop
         int n, ty0, tx0;
         tile_coords(tile, ntx, nty, n, ty0, tx0);
-        long long off[2][4];
+        // destination offset = wave-uniform tile part (64-bit, scalar unit) + lane-constant part loff (32-bit)
+        const long long tbase = (long long)n * a.dst_nstride + ((long long)(ty0 * a.out_step + a.out_oy[z]) * a.Wd + (tx0 * a.out_step + a.out_ox[z])) * 64;
         bool ok[2][4];
         uint4 rr[2][4], mm[2][4];
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
-            const int vy = ty0 + wave * 2 + rw;
-            const int oy = vy * a.out_step + a.out_oy[z];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int vx = tx0 + rpx + 8 * it;
-                ok[rw][it] = vy < a.H && vx < a.W;
-                const int ox = vx * a.out_step + a.out_ox[z];
-                off[rw][it] = (long long)n * a.dst_nstride + ((long long)oy * a.Wd + ox) * 64 + rch * 8;
-                if (HAS_RES && ok[rw][it]) rr[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + off[rw][it]);
-                if (MASK != MASK_NONE && ok[rw][it]) mm[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + off[rw][it]);
+                ok[rw][it] = (ty0 + wave * 2 + rw < a.H) && (tx0 + rpx + 8 * it < a.W);
+                if (HAS_RES && ok[rw][it]) rr[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + tbase + loff[rw][it]);
+                if (MASK != MASK_NONE && ok[rw][it]) mm[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[rw][it]);
             }
         }
         STAMP(t1);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     union { uint4 q; bf16_t hh[8]; } pk;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pk.hh[j] = (bf16_t)v[j];
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.dst[z]) + off[rw][it]) = pk.q;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.dst[z]) + tbase + loff[rw][it]) = pk.q;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
