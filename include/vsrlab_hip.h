@@ -85,6 +85,16 @@ int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* param
                        const float* ref, const float* supp, float* flow, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* ---- RealBasicVSR pre-clean stack, forward: lq = IterativeRefinement(lr) ----------------------
+ * (vsr/models/RealBasicVSR/realbasicvsr.py:17-30): `steps` times x <- x + conv(ResidualBlock(x)) on
+ * the F = n*t frames (F,3,h,w) fp32 planar.  params (4 + 4*blocks tensors): resblock.conv.0.{weight,
+ * bias}, resblock.res_block.{i}.conv1.{weight,bias}, conv2.{weight,bias} ..., conv.{weight,bias}.
+ * lq is a fresh tensor (the reference updates lr in place: SURVEY.md appendix A3).             */
+size_t vsr_cleaner_workspace_bytes(int F, int h, int w, int blocks, int dtype);
+int vsr_cleaner_forward(int F, int h, int w, int mid_channels, int blocks, int steps, int dtype,
+                        const float* const* params, int nparams, const float* lr, float* lq,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-op entry points (pixel-major tensors) --------------------------------------------- */
 /* flow_warp, zeros padding (spynet.py:95-106): out[n,y,x,:] = bilinear(in[n], x+fx, y+fy)     */
 int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H,

@@ -392,3 +392,16 @@ def fwd_bwd(sd: Mapping[str, Tensor], lrs: Tensor, hr: Tensor, train_flow: bool 
     (loss if cot is None else torch.mean(sr * cot)).backward()
     grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
     return sr.detach(), loss.detach(), grads
+
+
+def cleaner_param_shapes(mid_channels: int = 64, blocks: int = 20, prefix: str = "cleaner.") -> Dict[str, Tuple[int, ...]]:
+    """state_dict key -> shape of ``IterativeRefinement`` (realbasicvsr.py:18-22)."""
+    c = mid_channels
+    shapes: Dict[str, Tuple[int, ...]] = {f"{prefix}resblock.conv.0.weight": (c, 3, 3, 3), f"{prefix}resblock.conv.0.bias": (c,)}
+    for i in range(blocks):
+        for j in (1, 2):
+            shapes[f"{prefix}resblock.res_block.{i}.conv{j}.weight"] = (c, c, 3, 3)
+            shapes[f"{prefix}resblock.res_block.{i}.conv{j}.bias"] = (c,)
+    shapes[f"{prefix}conv.weight"] = (3, c, 3, 3)
+    shapes[f"{prefix}conv.bias"] = (3,)
+    return shapes

@@ -136,6 +136,14 @@ def main():
         sr, lq = m(lrs.clone())
     save("realbasicvsr_m16", seed_lr=12, sr=sr, lq=lq)
 
+    # the same at 64 channels (the width the HIP path is built for), ragged frame size
+    m = load_keyed(realbasicvsr.RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2,
+                                             pretrained_flow=False, train_flow=False))
+    lrs = rand(14, 1, 3, 3, 24, 40)
+    with torch.no_grad():
+        sr, lq = m(lrs.clone())
+    save("realbasicvsr_m64", seed_lr=14, sr=sr, lq=lq)
+
 
 if __name__ == "__main__":
     main()

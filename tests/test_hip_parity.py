@@ -343,3 +343,33 @@ def test_backward_is_linear_in_cotangent_large():
     # every product dY*X is formed from bf16-rounded activation gradients: linear up to bf16 rounding
     assert rel_l2(g12, 0.5 * g1 + g2) < 2e-2
     assert rel_l2(bwd(c1), g1) < 1e-3          # atomics in the warp scatter: order noise only
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_realbasicvsr_inference_vs_golden(dtype):
+    """``sr, lq = RealBasicVSR(lr)`` (the `_target_` of conf/train/model/basicvsr.yaml) under no_grad:
+    pre-clean stack + BasicVSR on the HIP engine, against the reference's own outputs; ragged 24x40 frames.
+    ``lq`` must be a fresh tensor (the input is not mutated) and training must raise, not fall back."""
+    dev = _gpu()
+    from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
+    g = golden("realbasicvsr_m64")
+    m = RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2, pretrained_flow=False, train_flow=False)
+    shapes = {"basicvsr." + k: s for k, s in O.basicvsr_param_shapes(64, 2, 4).items()}
+    shapes.update(O.cleaner_param_shapes(64, 2))
+    m.load_state_dict(O.keyed_state_dict(shapes), strict=True)
+    m = m.to(dev).eval()
+    m.basicvsr.compute_dtype = dtype
+    lrs = rand(g["seed_lr"], 1, 3, 3, 24, 40).to(dev)
+    keep = lrs.clone()
+    import os
+    os.environ["VSRLAB_AMD_DTYPE"] = dtype
+    try:
+        with torch.no_grad():
+            sr, lq = m(lrs)
+        with pytest.raises(NotImplementedError):
+            m(lrs)                                   # grad mode: the pre-clean backward is not on the HIP path
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]
+    assert torch.equal(lrs, keep) and lq.data_ptr() != lrs.data_ptr()
+    assert rel_err(lq, g["lq"]) < tol(dtype, 1e-3, 2e-2)
+    assert rel_err(sr, g["sr"]) < tol(dtype, 1e-3, 3e-2)

@@ -101,3 +101,15 @@ def test_realbasicvsr_forward():
         sr, lq = O.realbasicvsr_forward(sd, lrs)
     assert rel_err(lq, g["lq"]) < TOL
     assert rel_err(sr, g["sr"]) < TOL
+
+
+def test_realbasicvsr_forward_64_channels():
+    g = golden("realbasicvsr_m64")
+    shapes = {"basicvsr." + k: s for k, s in O.basicvsr_param_shapes(64, 2, 4).items()}
+    shapes.update(O.cleaner_param_shapes(64, 2))
+    sd = O.keyed_state_dict(shapes)
+    lrs = rand(g["seed_lr"], 1, 3, 3, 24, 40)
+    with torch.no_grad():
+        sr, lq = O.realbasicvsr_forward(sd, lrs)
+    assert rel_err(lq, g["lq"]) < TOL
+    assert rel_err(sr, g["sr"]) < TOL

@@ -634,6 +634,72 @@ int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* param
     return spynet_run(c, s.sp, c.fat(s.frames), params[60], params[61], N, 2, 1, flow);
 }
 
+// ---- RealBasicVSR pre-clean stack, forward (realbasicvsr.py:17-30) ------------------------------------
+// x <- x + conv(ResidualBlock(x)), `steps` times, on the F = n*t frames of the clip.
+// params: resblock.conv.0.{weight,bias}, resblock.res_block.{i}.conv{1,2}.{weight,bias} ..., conv.{weight,bias}
+struct CleanPlan { size_t stem_w, stem_b, out_w, out_b, feat, act, xa, xb, total; std::vector<size_t> blk_w, blk_b; };
+static CleanPlan clean_plan(int F, int h, int w, int blocks, int dtype) {
+    CleanPlan p; Bump b;
+    const size_t es = esize(dtype), w64 = (size_t)9 * C * C * es;
+    p.stem_w = b.take((size_t)9 * C * 16 * es); p.stem_b = b.take(C * 4);
+    p.blk_w.resize(2 * blocks); p.blk_b.resize(2 * blocks);
+    for (int k = 0; k < 2 * blocks; ++k) { p.blk_w[k] = b.take(w64); p.blk_b[k] = b.take(C * 4); }
+    p.out_w = b.take((size_t)9 * 32 * C * es); p.out_b = b.take(64 * 4);
+    const size_t a1 = (size_t)F * h * w * C * es;
+    p.feat = b.take(a1); p.act = b.take(a1);
+    p.xa = b.take((size_t)F * 3 * h * w * 4); p.xb = b.take((size_t)F * 3 * h * w * 4);
+    p.total = b.off;
+    return p;
+}
+
+size_t vsr_cleaner_workspace_bytes(int F, int h, int w, int blocks, int dtype) {
+    if (F < 1 || h < 1 || w < 1 || blocks < 0) return 0;
+    return clean_plan(F, h, w, blocks, dtype).total;
+}
+
+int vsr_cleaner_forward(int F, int h, int w, int mid_channels, int blocks, int steps, int dtype, const float* const* params,
+                        int nparams, const float* lr, float* lq, void* workspace, size_t workspace_bytes, void* stream) {
+    if (F < 1 || h < 1 || w < 1 || blocks < 0 || steps < 1 || !params || !lr || !lq || !workspace) return VSR_ERR_BADARG;
+    if (mid_channels != C) return VSR_ERR_UNSUPPORTED;
+    if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+    if (nparams != 4 + 4 * blocks) return VSR_ERR_BADARG;
+    const CleanPlan p = clean_plan(F, h, w, blocks, dtype);
+    if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Plan dummy; dummy.es = esize(dtype);
+    const Ctx c{dummy, (char*)workspace, st, dtype};
+    CK(c.pack(params[0], p.stem_w, 9, C, 16, C, 3, 3, 0, 1, 0, 0));
+    CK(c.pack_bias(params[1], p.stem_b, C));
+    for (int k = 0; k < 2 * blocks; ++k) {
+        CK(c.pack(params[2 + 2 * k], p.blk_w[k], 9, C, C, C, C, C, 0, 1, 0, 0));
+        CK(c.pack_bias(params[3 + 2 * k], p.blk_b[k], C));
+    }
+    CK(c.pack(params[2 + 4 * blocks], p.out_w, 9, 32, C, 3, C, C, 0, 1, 0, 0));
+    CK(c.pack_bias(params[3 + 4 * blocks], p.out_b, 3));
+    const float* xin = lr;
+    for (int s = 0; s < steps; ++s) {
+        float* xout = (s == steps - 1) ? lq : (float*)c.at((s & 1) ? p.xb : p.xa);
+        {   // ResidualBlock stem: conv3x3 3->64 + LeakyReLU(0.1) on the planar frames (conv.py:97)
+            ConvArgs a = c.base(F, h, w);
+            a.src[0] = xin; a.src_nstride[0] = (long long)3 * h * w;
+            a.wpack = c.at(p.stem_w); a.bias = c.fat(p.stem_b); a.dst[0] = c.at(p.feat); a.act = ACT_LEAKY;
+            CK(vsr_launch_conv(dtype, 3, 1, 16, 16, 1, 64, EPI_NHWC, a, st));
+        }
+        for (int b = 0; b < blocks; ++b) {
+            CK(c.conv64(c.at(p.feat), p.blk_w[2 * b], c.fat(p.blk_b[2 * b]), c.at(p.act), ACT_RELU, nullptr, nullptr, 0, F, h, w));
+            CK(c.conv64(c.at(p.act), p.blk_w[2 * b + 1], c.fat(p.blk_b[2 * b + 1]), c.at(p.feat), ACT_NONE, c.at(p.feat), nullptr, 0, F, h, w));
+        }
+        {   // x + conv3x3 64->3 (realbasicvsr.py:28-29; a fresh tensor instead of the reference's in-place +=)
+            ConvArgs a = c.base(F, h, w);
+            a.src[0] = c.at(p.feat); a.wpack = c.at(p.out_w); a.bias = c.fat(p.out_b); a.cout_real = 3;
+            a.dst[0] = xout; a.dst_nstride = (long long)3 * h * w; a.pres = xin;
+            CK(vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, st));
+        }
+        xin = xout;
+    }
+    return VSR_OK;
+}
+
 // ---- per-op entry points -------------------------------------------------------------------------
 int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H, int W, int Cc, void* stream) {
     return vsr_launch_warp_fwd(dtype, in_pm, flow, out_pm, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);

@@ -331,6 +331,32 @@ def basicvsr_flows(lrs_shape, mid_channels, res_blocks, upscale, ws: Workspace, 
 
 
 # --------------------------------------------------------------------------------------------- #
+# RealBasicVSR pre-clean stack, forward (reference: vsr/models/RealBasicVSR/realbasicvsr.py:17-30)
+# --------------------------------------------------------------------------------------------- #
+def cleaner_forward(params: Sequence[torch.Tensor], lr: torch.Tensor, mid_channels: int, blocks: int, steps: int = 3,
+                    compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """lq = IterativeRefinement(lr): (n,t,3,h,w) -> (n,t,3,h,w), a fresh tensor.  Inference only for now."""
+    _require_gpu(lr)
+    if torch.is_grad_enabled() and (lr.requires_grad or any(p.requires_grad for p in params)):
+        raise NotImplementedError("the backward of the RealBasicVSR pre-clean stack is not on the HIP path yet "
+                                  "(it needs the SPyNet input gradient); run it under torch.no_grad()")
+    if len(params) != 4 + 4 * blocks:
+        raise ValueError("expected the 4 + 4*blocks tensors of IterativeRefinement")
+    n, t, c, h, w = lr.shape
+    if c != 3:
+        raise ValueError("lr must be (n,t,3,h,w)")
+    dtype = resolve_dtype(compute_dtype)
+    lib = _lib.load()
+    ps = [_f32c(p) for p in params]
+    nbytes = lib.vsr_cleaner_workspace_bytes(n * t, h, w, blocks, dtype)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=lr.device)
+    lq = torch.empty((n, t, 3, h, w), dtype=torch.float32, device=lr.device)
+    _lib.check(lib.vsr_cleaner_forward(n * t, h, w, mid_channels, blocks, steps, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(lr)),
+                                       _ptr(lq), _ptr(ws), ws.numel(), _stream()), "cleaner_forward")
+    return lq
+
+
+# --------------------------------------------------------------------------------------------- #
 # Charbonnier loss (reference: core/losses.py:10-18), fused value + gradient
 # --------------------------------------------------------------------------------------------- #
 class _CharbonnierFn(torch.autograd.Function):

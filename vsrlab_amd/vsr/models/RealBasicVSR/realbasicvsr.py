@@ -1,11 +1,15 @@
 """``RealBasicVSR`` plugin surface (vsrlab ``src/vsr/models/RealBasicVSR/realbasicvsr.py:5-30``,
 the ``_target_`` of conf/train/model/basicvsr.yaml).  ``sr, lq = model(lr)``.
 
-The BasicVSR stage runs on the HIP engine.  The pre-clean stack (``IterativeRefinement``) keeps the
-reference's parameters and keys; its HIP kernels are the next row of the scope table,
-so a non-zero ``cleaning_blocks`` forward raises instead of silently falling back."""
+Both stages run on the HIP engine for inference (``torch.no_grad()``): the pre-clean stack reuses the
+trunk kernels (3->64 stem on the planar frames, 64->64 residual blocks, 64->3 conv with the ``x +``
+fused as a planar residual).  Training through the pre-clean stack needs the gradient w.r.t. the LR
+clip, incl. the path through SPyNet's inputs: that raises instead of silently
+falling back.  ``lq`` is a fresh tensor; the reference mutates ``lr`` in place and returns it
+(realbasicvsr.py:26-30) -- the values are identical."""
 import torch.nn as nn
 
+from .... import functional as VF
 from ....core.modules.conv import ResidualBlock
 from .modules.basicvsr import BasicVSR
 
@@ -14,11 +18,21 @@ class IterativeRefinement(nn.Module):
     def __init__(self, mid_ch, blocks, steps=3):
         super().__init__()
         self.steps = steps
+        self.mid_ch = mid_ch
+        self.blocks = blocks
         self.resblock = ResidualBlock(3, mid_ch, blocks)
         self.conv = nn.Conv2d(mid_ch, 3, 3, 1, 1, bias=True)
 
+    def _ordered_tensors(self):
+        sd = self.state_dict(keep_vars=True)
+        keys = ["resblock.conv.0.weight", "resblock.conv.0.bias"]
+        for i in range(self.blocks):
+            for j in (1, 2):
+                keys += [f"resblock.res_block.{i}.conv{j}.weight", f"resblock.res_block.{i}.conv{j}.bias"]
+        return [sd[k] for k in keys + ["conv.weight", "conv.bias"]]
+
     def forward(self, x):
-        raise NotImplementedError("the RealBasicVSR pre-clean stack is not on the HIP path yet (SURVEY.md 8f rank 1)")
+        return VF.cleaner_forward(self._ordered_tensors(), x, self.mid_ch, self.blocks, self.steps)
 
 
 class RealBasicVSR(nn.Module):
