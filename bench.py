@@ -82,8 +82,8 @@ def dominant_kernel_roofline(dev, h, w, iters=40):
     (torch's current stream), same shape and epilogues as inside the engine.  Algorithmic bytes per
     launch: X 64*P*2 + Y 64*P*2 (+ skip 64*P*2 on every second launch)."""
     from vsrlab_amd import functional as VF
-    x = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
-    r = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
+    x = VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16)
+    r = VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16)
     wgt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
     b = torch.zeros(64, device=dev)
     for _ in range(3):

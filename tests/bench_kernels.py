@@ -18,8 +18,8 @@ def main():
     from vsrlab_amd import functional as VF
     lib = vsrlab_amd._lib.load()
     dev = torch.device("cuda:0")
-    x = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
-    r = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
+    x = torch.randn(1, h, (w + 31) // 32, 8, 32, 8, device=dev).to(torch.bfloat16)
+    r = torch.randn(1, h, (w + 31) // 32, 8, 32, 8, device=dev).to(torch.bfloat16)
     y = torch.empty_like(x)
     wgt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
     b = torch.zeros(64, device=dev)

@@ -11,8 +11,8 @@ lib = ctypes.CDLL(os.path.join(ROOT, "vsrlab_amd", "lib", "libvsrlab_hip_stamps.
 P = ctypes.c_void_p
 h, w = 540, 960
 dev = torch.device("cuda:0")
-x = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
-r = torch.randn(1, h, w, 64, device=dev).to(torch.bfloat16)
+x = torch.randn(1, h, (w + 31) // 32, 8, 32, 8, device=dev).to(torch.bfloat16)
+r = torch.randn(1, h, (w + 31) // 32, 8, 32, 8, device=dev).to(torch.bfloat16)
 y = torch.empty_like(x)
 wgt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
 b = torch.zeros(64, device=dev)

@@ -55,7 +55,7 @@ def test_layout_roundtrip(dtype):
     dev = _gpu()
     x = rand(21, 2, 5, 9, 11, lo=-1, hi=1)
     pm = VF.to_pixel_major(x.to(dev), VF.resolve_dtype(dtype))
-    assert pm.shape == (2, 9, 11, 16)
+    assert pm.shape == (2, 9, 1, 2, 32, 8) and pm.pm_w == 11      # blocked: [N][H][W/32][C/8][32][8]
     back = VF.from_pixel_major(pm, 5).cpu()
     ref = x if dtype == "fp32" else bf16_round(x)
     assert torch.equal(back, ref)

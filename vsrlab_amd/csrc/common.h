@@ -88,6 +88,22 @@ struct WgradArgs {
 
 static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- the internal "pixel-major" layout, blocked by 32 pixels ---------------------------------------
+//   [N][H][WS = ceil(W/32)][C/8 chunks][32 pixels][8 channels]
+// i.e. inside a 32-pixel row segment the 16-byte (bf16) channel chunks of the 32 pixels are contiguous
+// (512 B per chunk).  This is exactly the MFMA accumulator layout of the conv kernels (lane = pixel of
+// a 32-pixel segment, registers = 4 consecutive channels), so epilogues store and read residuals with
+// fully coalesced wave instructions and no transposition; operand tiles are gathered by per-lane
+// addresses (LDS-DMA / staging loops), which costs nothing.  Rows are padded to whole segments; the
+// padding pixels are never read (loaders bound-check x < W) and never written.
+static inline __host__ __device__ int pm_ws(int W) { return (W + 31) >> 5; }
+static inline __host__ __device__ long long pm_image_elems(int H, int W, int C) { return (long long)H * pm_ws(W) * 32 * C; }
+// element offset of channel chunk `chunk` (8 channels) of pixel (y, x); x may be negative (halo)
+static inline __host__ __device__ long long pm_off(int y, int x, int chunk, int W, int C) {
+    const int seg = x >> 5;                       // arithmetic shift: floor
+    return (((long long)y * pm_ws(W) + seg) * (C >> 3) + chunk) * 256 + (x & 31) * 8;
+}
+
 #define HIP_CHECK_RET(expr)                                   \
     do {                                                      \
         hipError_t _e = (expr);                               \

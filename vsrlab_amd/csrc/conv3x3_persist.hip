@@ -1,4 +1,4 @@
-// The hot kernel of the path: 3x3, 64 -> 64 channels, bf16 in / fp32 accumulate, pixel-major.
+// The hot kernel of the path: 3x3, 64 -> 64 channels, bf16 in / fp32 accumulate.
 //   core/modules/conv.py:85-86 (ResidualConv conv1/conv2), basicvsr.py:20 (conv_last.0),
 //   upsampling.py:7 (as 4 pixel-shuffle phases), and all their data gradients: > 70 % of the FLOPs.
 //
@@ -6,22 +6,23 @@
 // 15 us on the matrix cores -- the kernel is HBM-bound, and a CU needs ~75 KB in flight to cover ~3 us of
 // loaded HBM latency.  Design for one MI355X CU (160 KiB LDS, 4 SIMDs):
 //   * ONE 256-thread workgroup per CU (one wave per SIMD, up to 512 VGPRs each), grid = #CUs, persistent
-//     over 8x32-pixel tiles.  The packed weights [9 taps][64 cout][64 cin] bf16 (72 KiB) are loaded into LDS
-//     once and stay.
+//     over 8x32-pixel tiles (one 32-pixel segment of the blocked layout wide, see common.h).  The packed
+//     weights [9 taps][64 cout][64 cin] bf16 (72 KiB) are loaded into LDS once and stay.
 //   * the haloed 10x34-pixel input tile is DOUBLE-BUFFERED in LDS (2 x 42.5 KiB) and filled by LDS-DMA
 //     (global_load_lds_dwordx4) one whole tile ahead; the residual / mask operands of the epilogue are
 //     requested into registers before the K loop.  Nothing the tile needs is waited for at first use.
 //   * K loop: 144 v_mfma_f32_32x32x16_bf16 per wave and tile, no barrier inside; A (weights) and B (pixels)
-//     fragments are ds_read_b128 at register base + immediate, requested two k-steps ahead of their MFMAs
-//     (explicit 3-deep ring, order pinned with sched_group_barrier: a lone wave per SIMD has nobody to hide
-//     an LDS round trip behind).  Both LDS images are XOR-swizzled on the 16-byte chunk (weights by cout
-//     row, pixels by x only => a ky shift is an immediate); the pixel swizzle is applied on the DMA's
-//     per-lane SOURCE address.  SQ_LDS_BANK_CONFLICT = 0 measured.
-//   * epilogue: the accumulator layout (lane = pixel, registers = channels) would store 8-byte pieces into
-//     32 different 128-byte lines per instruction (measured: as expensive as the K loop).  Each wave
-//     transposes its rows through a private 8 KiB fp32 slot of the tile buffer it has just finished with and
-//     writes whole 128-byte pixel lines, 16 bytes per lane.  Fused: bias, ReLU / LeakyReLU(0.1), residual
-//     add, activation-gradient mask, pixel-shuffle placement; one rounding to bf16 at the very end.
+//     fragments are ds_read_b128 at register base + immediate, issued by hand two k-steps ahead of their
+//     MFMAs (inline asm + counted s_waitcnt: a lone wave per SIMD has nobody to hide an LDS round trip
+//     behind, and hipcc sinks builtin LDS reads back in front of their consumers).  Both LDS images are
+//     [row][8 chunks of 16 B], XOR-swizzled on the chunk (weights by cout row, pixels by x only => a ky
+//     shift is an immediate); the pixel swizzle and the gather out of the blocked global layout are applied
+//     on the DMA's per-lane SOURCE address.  SQ_LDS_BANK_CONFLICT = 0 measured.
+//   * epilogue: the accumulator layout (lane = pixel of the segment, registers = 4 consecutive channels) IS
+//     the blocked global layout, so bias / ReLU / LeakyReLU(0.1) / residual add / activation-gradient mask /
+//     pixel-shuffle placement are applied in registers and every store (and residual / mask load) is a wave
+//     instruction over 512 contiguous bytes.  (With plain [pixel][64 ch] rows the same stores hit 32 lines
+//     per instruction and cost as much as the K loop; an LDS transposition cost 2.7 k cycles per tile.)
 #include "common.h"
 
 namespace {
@@ -29,9 +30,8 @@ namespace {
 constexpr int PTW = 32, PTH = 8, PNT = 256;
 constexpr int PTWH = PTW + 2, PTHH = PTH + 2, PNPIX = PTHH * PTWH;       // 34 x 10 = 340 haloed pixels
 constexpr int W_BYTES = 9 * 64 * 64 * 2;                                  // 73,728
-constexpr int IN_BYTES = PNPIX * 128;                                     // 43,520 per buffer (>= 4 waves x 8 KiB slots)
-constexpr int BIAS_BYTES = 256;                                           // 64 fp32
-constexpr int P_LDS = W_BYTES + 2 * IN_BYTES + BIAS_BYTES;                // 161,024 <= 163,840
+constexpr int IN_BYTES = PNPIX * 128;                                     // 43,520 per buffer
+constexpr int P_LDS = W_BYTES + 2 * IN_BYTES;                             // 160,768 <= 163,840
 constexpr int IN_CHUNKS = PNPIX * 8;                                      // 2,720 16-byte chunks
 constexpr int NPIECE_T = (IN_CHUNKS + 63) / 64;                           // 43 DMA pieces of 1 KiB (last half full)
 constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11 per wave
@@ -71,11 +71,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntx, int nty, int& n, 
     tx0 = (r - ty * ntx) * PTW;
 }
 
-__device__ __forceinline__ void unpack_bf8(const uint4& u, float* f) {
-    union { uint4 q; bf16_t h[8]; } t; t.q = u;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (float)t.h[j];
-}
+struct __attribute__((aligned(8))) bf4 { bf16_t v[4]; };
 
 #define GLDS16(src, dst)                                                                              \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
@@ -90,12 +86,11 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     const int l31 = lane & 31, h = lane >> 5;
     char* lds_w = smem;
     char* lds_t = smem + W_BYTES;                                         // two tile buffers
-    float* lds_bias = reinterpret_cast<float*>(smem + W_BYTES + 2 * IN_BYTES);
 
     const int z = blockIdx.y;
     const int ntx = cdiv(a.W, PTW), nty = cdiv(a.H, PTH);
     const int total = a.N * ntx * nty;
-    if (tid < 64) lds_bias[tid] = a.bias ? a.bias[(long long)z * a.bias_zstride + tid] : 0.f;
+    const int WSs = pm_ws(a.W), WSd = pm_ws(a.Wd);
 
     // ---- weights of this z: global [tap][cout][cin] -> LDS, chunk c of row r at (r*8 + (c ^ ((r>>1)&7))) ----
     {
@@ -107,9 +102,19 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[idx];
         }
     }
+    // this lane's 32 bias values in accumulator layout (couts cb*32 + 8g + 4h + j)
+    float4 breg[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            breg[cb][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long long)z * a.bias_zstride + cb * 32 + 8 * g + 4 * h)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- DMA pieces of this wave: piece = wave + 4 i.  LDS slot (pixel p, position q) of a piece receives
-    // global chunk q ^ ((tx>>1)&7) of pixel p; rel[i] = this lane's source byte offset from the tile origin ----
+    // ---- DMA pieces of this wave: piece = wave + 4 i.  LDS slot (tile pixel p = (ty,tx), position q) receives
+    // global chunk q ^ ((tx>>1)&7) of that pixel; rel[i] = its source BYTE offset from the tile origin
+    // pm_off(ty0, tx0) in the blocked layout (tx0 is a multiple of 32: one segment per tile row, the halo
+    // columns are the last / first pixel of the neighbouring segments) ----
     const char* src = reinterpret_cast<const char*>(a.src[0]);
     const char* zsrc = reinterpret_cast<const char*>(g_conv_zero_chunk);
     int rel[NPIECE_W];
@@ -118,12 +123,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         const int idx = (wave + 4 * i) * 64 + lane;
         const int p = idx >> 3;
         const int ty = p / PTWH, tx = p - ty * PTWH;
-        rel[i] = (((ty - 1) * a.W + (tx - 1)) * 64 + ((idx & 7) ^ ((tx >> 1) & 7)) * 8) * 2;
+        const int dx = tx - 1, c = (idx & 7) ^ ((tx >> 1) & 7);
+        rel[i] = ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
     }
     auto issue = [&](int tile, int buf) {
         int n, ty0, tx0;
         tile_coords(tile, ntx, nty, n, ty0, tx0);
-        const char* org = src + ((long long)n * a.src_nstride[0] + ((long long)ty0 * a.W + tx0) * 64) * 2;
+        const char* org = src + ((long long)n * a.src_nstride[0] + pm_off(ty0, tx0, 0, a.W, 64)) * 2;
         char* dstb = lds_t + buf * IN_BYTES;
         if (ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W) {          // interior tile (wave-uniform)
 #pragma unroll
@@ -161,13 +167,15 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             const int tx = l31 + kx;
             b_off[kx][ks] = ((wave * 2 * PTWH + tx) * 8 + ((2 * ks + h) ^ ((tx >> 1) & 7))) * 16;
         }
-    const int rpx = lane >> 3, rch = lane & 7;            // epilogue role: pixel rpx + 8*it, channels 8*rch..8*rch+7
-    int loff[2][4];                                       // lane-constant part of the destination element offset
+    // epilogue: lane-constant part of the destination element offset of this lane's 4-channel group, per row:
+    // pixel (dy, dx) relative to the tile's destination origin pm_off(ty0*os + ooy, tx0*os) (tx0*os is a multiple of 32)
+    int loff[2];
+    {
+        const int dx = l31 * a.out_step + a.out_ox[z];
 #pragma unroll
-    for (int rw = 0; rw < 2; ++rw)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            loff[rw][it] = (((wave * 2 + rw) * a.out_step) * a.Wd + (rpx + 8 * it) * a.out_step) * 64 + rch * 8;
+        for (int rw = 0; rw < 2; ++rw)
+            loff[rw] = ((((wave * 2 + rw) * a.out_step) * WSd + (dx >> 5)) * 8) * 256 + (dx & 31) * 8 + 4 * h;
+    }
 
 #ifdef VSR_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -176,34 +184,32 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     int tile = blockIdx.x;
     if (tile < total) issue(tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                       // weights, bias and the first tile are in LDS
-
-    float4 breg[2][4];                                    // this lane's 32 bias values (accumulator layout), for the whole launch
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) breg[cb][g] = *reinterpret_cast<const float4*>(lds_bias + cb * 32 + 8 * g + 4 * h);
+    __syncthreads();                                       // weights and the first tile are in LDS
 
     for (; tile < total; tile += gridDim.x) {
         STAMP(t0);
         const int next = tile + gridDim.x;
         if (next < total) issue(next, cur ^ 1);            // a whole tile ahead of the MFMAs
-        const char* lds_in = lds_t + cur * IN_BYTES;
 
         // epilogue operands, requested now, used after the K loop
         int n, ty0, tx0;
         tile_coords(tile, ntx, nty, n, ty0, tx0);
-        // destination offset = wave-uniform tile part (64-bit, scalar unit) + lane-constant part loff (32-bit)
-        const long long tbase = (long long)n * a.dst_nstride + ((long long)(ty0 * a.out_step + a.out_oy[z]) * a.Wd + (tx0 * a.out_step + a.out_ox[z])) * 64;
-        bool ok[2][4];
-        uint4 rr[2][4], mm[2][4];
+        const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oy[z], tx0 * a.out_step, 0, a.Wd, 64);
+        const bool okx = tx0 + l31 < a.W;
+        bool ok[2];
+        bf4 rr[2][2][4], mm[2][2][4];
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
+            ok[rw] = okx && (ty0 + wave * 2 + rw < a.H);
+            if (ok[rw]) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                ok[rw][it] = (ty0 + wave * 2 + rw < a.H) && (tx0 + rpx + 8 * it < a.W);
-                if (HAS_RES && ok[rw][it]) rr[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + tbase + loff[rw][it]);
-                if (MASK != MASK_NONE && ok[rw][it]) mm[rw][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[rw][it]);
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const long long o = tbase + loff[rw] + (cb * 4 + g) * 256;
+                        if (HAS_RES) rr[rw][cb][g] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + o);
+                        if (MASK != MASK_NONE) mm[rw][cb][g] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
+                    }
             }
         }
         STAMP(t1);
@@ -217,10 +223,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                 for (int i = 0; i < 16; ++i) acc[cb][rw][i] = 0.f;
 
         // ---- K loop: 36 steps s = (tap, ks) of 4 MFMAs.  The 4 fragment reads of step s+2 are issued before
-        // the MFMAs of step s, by hand: the reads are inline asm with a counted s_waitcnt (lgkmcnt(8) = "all
-        // but the 8 youngest LDS reads have returned" = step s is in registers), because hipcc's scheduler
-        // sinks builtin LDS reads back in front of their consumers (measured: ds_read x4, lgkmcnt(0), mfma x4).
-        // A lone wave per SIMD has nobody else to hide an LDS round trip behind.
+        // the MFMAs of step s, by hand: lgkmcnt(8) = "all but the 8 youngest LDS reads have returned" = step s
+        // is in registers. ----
         bf16x8_t fa[3][2], fb[3][2];
         unsigned bb[3][4];                                   // B base addresses of this tile's buffer
 #pragma unroll
@@ -266,65 +270,41 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #undef CV_LOAD
 #undef DSR
         STAMP(t2);
-        __syncthreads();                 // every wave has finished reading this tile: its buffer is free for the slots
-        STAMP(t3);
 
-        // ---- epilogue ----
-        char* slot = lds_t + cur * IN_BYTES + wave * 8192;   // fp32 [32 pixels][64 ch], chunk q of pixel px at q ^ (px & 15)
+        // ---- epilogue, entirely in registers; every store covers 512 contiguous bytes per wave ----
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
+            if (ok[rw]) {
+                bf16_t* dst = reinterpret_cast<bf16_t*>(a.dst[z]) + tbase + loff[rw];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = cb * 32 + 8 * g + 4 * h;
-                    const float4 b = breg[cb][g];
-                    float4 v;
-                    v.x = p_act<ACT>(acc[cb][rw][4 * g + 0] + b.x); v.y = p_act<ACT>(acc[cb][rw][4 * g + 1] + b.y);
-                    v.z = p_act<ACT>(acc[cb][rw][4 * g + 2] + b.z); v.w = p_act<ACT>(acc[cb][rw][4 * g + 3] + b.w);
-                    *reinterpret_cast<float4*>(slot + l31 * 256 + (((co >> 2) ^ (l31 & 15)) << 4)) = v;
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float4 lo[4], hi[4];                          // all 8 reads in flight together: one LDS round trip per row
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+                        v[0] = p_act<ACT>(acc[cb][rw][4 * g + 0] + breg[cb][g].x); v[1] = p_act<ACT>(acc[cb][rw][4 * g + 1] + breg[cb][g].y);
+                        v[2] = p_act<ACT>(acc[cb][rw][4 * g + 2] + breg[cb][g].z); v[3] = p_act<ACT>(acc[cb][rw][4 * g + 3] + breg[cb][g].w);
+                        if (HAS_RES) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int px = rpx + 8 * it;
-                lo[it] = *reinterpret_cast<const float4*>(slot + px * 256 + (((2 * rch) ^ (px & 15)) << 4));
-                hi[it] = *reinterpret_cast<const float4*>(slot + px * 256 + (((2 * rch + 1) ^ (px & 15)) << 4));
-            }
+                            for (int j = 0; j < 4; ++j) v[j] += (float)rr[rw][cb][g].v[j];
+                        }
+                        if (MASK != MASK_NONE) {
+                            constexpr float neg = MASK == MASK_LEAKY ? 0.1f : 0.f;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (ok[rw][it]) {
-                    float v[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
-                    if (HAS_RES) {
-                        float r[8];
-                        unpack_bf8(rr[rw][it], r);
+                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mm[rw][cb][g].v[j] > 0.f ? 1.f : neg);
+                        }
+                        bf4 o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += r[j];
+                        for (int j = 0; j < 4; ++j) o.v[j] = (bf16_t)v[j];
+                        *reinterpret_cast<bf4*>(dst + (cb * 4 + g) * 256) = o;
                     }
-                    if (MASK != MASK_NONE) {
-                        float m[8];
-                        unpack_bf8(mm[rw][it], m);
-                        constexpr float neg = MASK == MASK_LEAKY ? 0.1f : 0.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] *= (m[j] > 0.f ? 1.f : neg);
-                    }
-                    union { uint4 q; bf16_t hh[8]; } pk;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pk.hh[j] = (bf16_t)v[j];
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.dst[z]) + tbase + loff[rw][it]) = pk.q;
-                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-        STAMP(t4);
+        STAMP(t3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (this wave's pieces)
-        __syncthreads();                                      // ... everybody's; the slots are no longer read
+        __syncthreads();                                      // ... everybody's; and everybody has finished reading `cur`
         cur ^= 1;
-        STAMP(t5);
-        STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5);
+        STAMP(t4);
+        STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
     }
 #ifdef VSR_STAMPS
     if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
@@ -357,15 +337,16 @@ extern "C" int vsr_debug_read_stamps(unsigned long long* host_out) {
 }
 #endif
 
-// Eligibility is decided by the dispatcher in conv_mfma.hip (bf16, 3x3, one pixel-major 64-channel
-// source at unit step, 64 output channels, pixel-major destination).  Returns VSR_ERR_UNSUPPORTED for
-// an epilogue combination that has no instantiation; the caller then uses the generic kernel.
+// Eligibility is decided by the dispatcher in conv_mfma.hip (bf16, 3x3, one 64-channel source at unit
+// step, 64 output channels, blocked pixel-major destination).  Returns VSR_ERR_UNSUPPORTED for an epilogue
+// combination that has no instantiation; the caller then uses the generic kernel.
 int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
     bool res = false, aux = false;
     for (int z = 0; z < a.nz; ++z) { res = res || a.res[z]; aux = aux || a.aux[z]; }
     for (int z = 0; z < a.nz; ++z) if ((res && !a.res[z]) || (aux && !a.aux[z])) return VSR_ERR_UNSUPPORTED;
     const int mask = aux ? a.mask_mode : MASK_NONE;
-    if ((long long)(PTHH + 1) * a.W * 128 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;   // in-tile byte offsets are 32-bit
+    if (pm_image_elems(PTHH + 2, a.W, 64) * 2 > 0x7fffffffLL || pm_image_elems(2 * PTH + 2, a.Wd, 64) > 0x7fffffffLL)
+        return VSR_ERR_UNSUPPORTED;                                                  // in-tile offsets are 32-bit
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
     PERSIST_CASE(ACT_RELU, false, MASK_NONE)     // conv1 of a ResidualConv
     PERSIST_CASE(ACT_NONE, true, MASK_NONE)      // conv2 + skip ; dgrad(conv1) + dX

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                     const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
                     chunk_t v = zero_chunk<T>();
                     if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = ((long long)(vy * a.in_step + a.src_oy[s]) * a.Ws + (vx * a.in_step + a.src_ox[s])) * C + c * 8;
+                        const long long o = pm_off(vy * a.in_step + a.src_oy[s], vx * a.in_step + a.src_ox[s], c, a.Ws, C);
                         v = *reinterpret_cast<const chunk_t*>(base + o);
                     }
                     int sc;
@@ -274,7 +274,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
         const int oy = vy * a.out_step + a.out_oy[z];
         const int ox = vx * a.out_step + a.out_ox[z];
         if (EPI == EPI_NHWC) {
-            const long long pix = (long long)n * a.dst_nstride + ((long long)oy * a.Wd + ox) * a.CD;
+            // blocked pixel-major destination: chunk (co>>3) of pixel (oy,ox), then channel (co&7) inside it;
+            // for out_step == 1 a wave instruction below covers 512 contiguous bytes
+            const long long pix = (long long)n * a.dst_nstride + pm_off(oy, ox, 0, a.Wd, a.CD);
             T* dst = reinterpret_cast<T*>(a.dst[z]) + pix;
             const T* res = a.res[z] ? reinterpret_cast<const T*>(a.res[z]) + pix : nullptr;
             const T* aux = a.aux[z] ? reinterpret_cast<const T*>(a.aux[z]) + pix : nullptr;
@@ -294,12 +296,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], a.act);
                     if (res) {
-                        const Vec4<T> r = *reinterpret_cast<const Vec4<T>*>(res + co);
+                        const Vec4<T> r = *reinterpret_cast<const Vec4<T>*>(res + (co >> 3) * 256 + (co & 7));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += to_f(r.v[j]);
                     }
                     if (aux) {
-                        const Vec4<T> m = *reinterpret_cast<const Vec4<T>*>(aux + co);
+                        const Vec4<T> m = *reinterpret_cast<const Vec4<T>*>(aux + (co >> 3) * 256 + (co & 7));
                         const float neg = a.mask_mode == MASK_LEAKY ? 0.1f : 0.f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= (to_f(m.v[j]) > 0.f ? 1.f : neg);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                     Vec4<T> o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o.v[j] = (T)v[j];
-                    *reinterpret_cast<Vec4<T>*>(dst + co) = o;
+                    *reinterpret_cast<Vec4<T>*>(dst + (co >> 3) * 256 + (co & 7)) = o;
                 }
             }
         } else {

@@ -62,21 +62,21 @@ __global__ void warp_fwd_kernel(const T* __restrict__ in, const float* __restric
         float accv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) accv[j] = 0.f;
-        const T* img = in + (long long)n * H * W * C;
+        const T* img = in + (long long)n * pm_image_elems(H, W, C);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
             const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
             if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
                 float f[8];
-                unpack8(*reinterpret_cast<const chunk_t*>(img + ((long long)yi * W + xi) * C + c * 8), f);
+                unpack8(*reinterpret_cast<const chunk_t*>(img + pm_off(yi, xi, c, W, C)), f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) accv[j] += f[j] * wgt;
             }
         }
         chunk_t o;
         pack8(accv, o);
-        *reinterpret_cast<chunk_t*>(out + pix * C + c * 8) = o;
+        *reinterpret_cast<chunk_t*>(out + (long long)n * pm_image_elems(H, W, C) + pm_off(y, x, c, W, C)) = o;
     }
 }
 
@@ -99,8 +99,8 @@ __global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restr
         const float fx0 = floorf(px), fy0 = floorf(py);
         const int x0 = (int)fx0, y0 = (int)fy0;
         const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-        const float g = (float)dout[idx];
-        float* img = dacc + (long long)n * H * W * C;
+        const float g = (float)dout[(long long)n * pm_image_elems(H, W, C) + pm_off(y, x, c >> 3, W, C) + (c & 7)];
+        float* img = dacc + (long long)n * H * W * C;              // the fp32 accumulator stays plain [N][H][W][C]: 256-byte atomics
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
@@ -110,14 +110,30 @@ __global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restr
     }
 }
 
-// out = T(a + s)   (a: T or null, s: fp32 or null)
+// out = T(a + s)   a, out: blocked pixel-major T (a may be null); s: plain [N][H][W][C] fp32 (the warp scatter
+// accumulator) or null.  One thread per (pixel, 8-channel chunk).
 template <typename T>
-__global__ void add_cast_kernel(const T* __restrict__ a, const float* __restrict__ s, T* __restrict__ out, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        if (a) v += (float)a[i];
-        if (s) v += s[i];
-        out[i] = (T)v;
+__global__ void add_cast_kernel(const T* __restrict__ a, const float* __restrict__ s, T* __restrict__ out, int N, int H, int W, int C) {
+    typedef typename EW<T>::chunk_t chunk_t;
+    const int CP = C / 8;
+    const long long total = (long long)N * H * W * CP;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CP);
+        const long long pix = idx / CP;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        const long long o = (long long)n * pm_image_elems(H, W, C) + pm_off(y, x, c, W, C);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a) unpack8(*reinterpret_cast<const chunk_t*>(a + o), v);
+        if (s) {
+            const float4* sp = reinterpret_cast<const float4*>(s + pix * C + c * 8);
+            const float4 s0 = sp[0], s1 = sp[1];
+            v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+        }
+        chunk_t r;
+        pack8(v, r);
+        *reinterpret_cast<chunk_t*>(out + o) = r;
     }
 }
 
@@ -130,7 +146,9 @@ __global__ void planar_to_pm_kernel(const float* __restrict__ in, T* __restrict_
         const long long pix = idx / C;
         const long long hw = pix % ((long long)H * W);
         const int n = (int)(pix / ((long long)H * W));
-        out[idx] = (T)(c < Cin ? in[((long long)n * Cin + c) * H * W + hw] : 0.f);
+        const int y = (int)(hw / W), x = (int)(hw % W);
+        out[(long long)n * pm_image_elems(H, W, C) + pm_off(y, x, c >> 3, W, C) + (c & 7)] =
+            (T)(c < Cin ? in[((long long)n * Cin + c) * H * W + hw] : 0.f);
     }
 }
 template <typename T>
@@ -140,7 +158,7 @@ __global__ void pm_to_planar_kernel(const T* __restrict__ in, float* __restrict_
         const long long hw = idx % ((long long)H * W);
         const int c = (int)((idx / ((long long)H * W)) % Cout);
         const int n = (int)(idx / ((long long)H * W * Cout));
-        out[idx] = (float)in[((long long)n * H * W + hw) * C + c];
+        out[idx] = (float)in[(long long)n * pm_image_elems(H, W, C) + pm_off((int)(hw / W), (int)(hw % W), c >> 3, W, C) + (c & 7)];
     }
 }
 
@@ -249,8 +267,9 @@ __global__ void spynet_prepare_kernel(const float* __restrict__ frames, const fl
         float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         pack8(v, lo);
         pack8(z, hi);
-        typename EW<T>::chunk_t* o = reinterpret_cast<typename EW<T>::chunk_t*>(x16 + idx * 16);
-        o[0] = lo; o[1] = hi;
+        T* o = x16 + (long long)p * pm_image_elems(h, w, 16);
+        *reinterpret_cast<typename EW<T>::chunk_t*>(o + pm_off(y, x, 0, w, 16)) = lo;
+        *reinterpret_cast<typename EW<T>::chunk_t*>(o + pm_off(y, x, 1, w, 16)) = hi;
     }
 }
 
@@ -333,8 +352,9 @@ int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* d
     return VSR_OK;
 }
 
-int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, long long n, hipStream_t st) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(add_cast_kernel<T>, dim3(grid_for(n)), dim3(256), 0, st, (const T*)a, s, (T*)out, n));
+int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, int N, int H, int W, int C, hipStream_t st) {
+    const long long total = (long long)N * H * W * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(add_cast_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)a, s, (T*)out, N, H, W, C));
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

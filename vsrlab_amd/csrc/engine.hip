@@ -45,8 +45,9 @@ struct SpyPlan {
             pyr[l] = b.take((size_t)F * 3 * (hu >> s) * (wu >> s) * 4);
         }
         const size_t px = (size_t)P * hu * wu;
-        x16 = b.take(px * 16 * es); b32a = b.take(px * 32 * es); b64 = b.take(px * 64 * es);
-        b32b = b.take(px * 32 * es); b16 = b.take(px * 16 * es);
+        auto pm = [&](int Cc) { return (size_t)P * pm_image_elems(hu, wu, Cc) * es; };     // blocked pixel-major tensors
+        x16 = b.take(pm(16)); b32a = b.take(pm(32)); b64 = b.take(pm(64));
+        b32b = b.take(pm(32)); b16 = b.take(pm(16));
         flow_a = b.take(px * 2 * 4); flow_b = b.take(px * 2 * 4); flow_up = b.take(px * 2 * 4);
         for (int l = 0; l < 6; ++l)
             for (int j = 0; j < NSPY; ++j) {
@@ -61,7 +62,8 @@ struct Plan {
     bool bwd;
     int rb, n, t, h, w, dtype;
     size_t es;
-    size_t px1;                 // elements of one (n,h,w,64) tensor
+    size_t px1;                 // elements of one blocked (n,h,w,64) tensor
+    size_t s_elems;             // elements of the plain fp32 warp-scatter accumulator (n,h,w,64)
     // packed weights / biases
     size_t stem_w[2], stem_wd[2], stem_b[2];
     std::vector<size_t> blk_w[2], blk_wd[2], blk_b[2];     // [2*rb]: conv1, conv2 alternating
@@ -93,7 +95,9 @@ struct Plan {
         if (d.mid_channels != C || d.upscale != 4 || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
         if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
         es = esize(dtype);
-        px1 = (size_t)n * h * w * C;
+        px1 = (size_t)n * pm_image_elems(h, w, C);
+        s_elems = (size_t)n * h * w * C;
+        const size_t a2 = (size_t)n * pm_image_elems(2 * h, 2 * w, C) * es, a4 = (size_t)n * pm_image_elems(4 * h, 4 * w, C) * es;
         Bump b;
         const size_t w64 = (size_t)9 * C * C * es;
         for (int dir = 0; dir < 2; ++dir) {
@@ -127,7 +131,7 @@ struct Plan {
         scratchA = b.take(a1); scratchW = b.take(a1);
         const int nrec = bwd ? t : 1;
         Pt.assign(t, 0); U0.assign(t, 0); U1.assign(t, 0); C0.assign(t, 0);
-        for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(4 * a1); U1[i] = b.take(16 * a1); C0[i] = b.take(16 * a1); }
+        for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
         for (int i = nrec; i < t; ++i) { Pt[i] = Pt[0]; U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; }
         if (bwd) {
             for (int dir = 0; dir < 2; ++dir) {
@@ -140,8 +144,8 @@ struct Plan {
             }
             dFeatB.assign(t, 0);
             for (int i = 0; i < t; ++i) dFeatB[i] = b.take(a1);
-            dFF = b.take(a1); S = b.take(px1 * 4); dWp = b.take(a1);
-            G_C0 = b.take(16 * a1); G_U1 = b.take(16 * a1); G_U0 = b.take(4 * a1); G_P = b.take(a1);
+            dFF = b.take(a1); S = b.take(s_elems * 4); dWp = b.take(a1);
+            G_C0 = b.take(a4); G_U1 = b.take(a4); G_U0 = b.take(a2); G_P = b.take(a1);
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
             slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
@@ -164,8 +168,8 @@ struct Ctx {
     ConvArgs base(int N, int H, int W) const {
         ConvArgs a = {};
         a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1;
-        a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C; a.dst_nstride = (long long)H * W * C;
-        for (int s = 0; s < VSR_MAX_SRC; ++s) a.src_nstride[s] = (long long)H * W * C;
+        a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C; a.dst_nstride = pm_image_elems(H, W, C);
+        for (int s = 0; s < VSR_MAX_SRC; ++s) a.src_nstride[s] = pm_image_elems(H, W, C);
         return a;
     }
     // y = act(conv3x3(x) + bias) (+res) (*mask(aux)) -- 64 -> 64 at one resolution
@@ -179,7 +183,7 @@ struct Ctx {
     int conv_ps(const void* x, size_t wpack, const float* bias4, void* y, int N, int H, int W) const {
         ConvArgs a = base(N, H, W);
         a.src[0] = x; a.wpack = at(wpack); a.w_zstride = 9 * C * C; a.bias = bias4; a.bias_zstride = C; a.nz = 4;
-        a.out_step = 2; a.Hd = 2 * H; a.Wd = 2 * W; a.dst_nstride = (long long)4 * H * W * C;
+        a.out_step = 2; a.Hd = 2 * H; a.Wd = 2 * W; a.dst_nstride = pm_image_elems(2 * H, 2 * W, C);
         for (int z = 0; z < 4; ++z) { a.dst[z] = y; a.out_oy[z] = z >> 1; a.out_ox[z] = z & 1; }
         return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
     }
@@ -187,7 +191,7 @@ struct Ctx {
     int conv_ps_dgrad(const void* dy, size_t wpackd, void* dx, const void* aux, int mask, int N, int H, int W) const {
         ConvArgs a = base(N, H, W);
         a.nz = 1; a.in_step = 2; a.Hs = 2 * H; a.Ws = 2 * W;
-        for (int s = 0; s < 4; ++s) { a.src[s] = dy; a.src_oy[s] = s >> 1; a.src_ox[s] = s & 1; a.src_nstride[s] = (long long)4 * H * W * C; }
+        for (int s = 0; s < 4; ++s) { a.src[s] = dy; a.src_oy[s] = s >> 1; a.src_ox[s] = s & 1; a.src_nstride[s] = pm_image_elems(2 * H, 2 * W, C); }
         a.wpack = at(wpackd); a.dst[0] = dx; a.aux[0] = aux; a.mask_mode = mask;
         return vsr_launch_conv(dtype, 3, 4, 64, 64, 0, 64, EPI_NHWC, a, st);
     }
@@ -252,11 +256,11 @@ int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float
         const size_t bufs[NSPY + 1] = {sp.x16, sp.b32a, sp.b64, sp.b32b, sp.b16, 0};
         for (int j = 0; j < NSPY; ++j) {
             ConvArgs a = c.base(P, hl, wl);
-            a.src[0] = c.at(bufs[j]); a.src_nstride[0] = (long long)hl * wl * SPY_CIP[j];
+            a.src[0] = c.at(bufs[j]); a.src_nstride[0] = pm_image_elems(hl, wl, SPY_CIP[j]);
             a.wpack = c.at(sp.wpack[l][j]); a.bias = c.fat(sp.bias[l][j]); a.act = ACT_RELU;   // ReLU after the LAST conv too (spynet.py:16-18)
             a.cout_real = SPY_CO[j];
             if (j < NSPY - 1) {
-                a.dst[0] = c.at(bufs[j + 1]); a.CD = SPY_CD[j]; a.dst_nstride = (long long)hl * wl * SPY_CD[j];
+                a.dst[0] = c.at(bufs[j + 1]); a.CD = SPY_CD[j]; a.dst_nstride = pm_image_elems(hl, wl, SPY_CD[j]);
                 CK(vsr_launch_conv(c.dtype, 7, 1, SPY_CIP[j], SPY_CIP[j], 0, SPY_COP[j], EPI_NHWC, a, c.st));
             } else {
                 a.dst[0] = c.at(fcur); a.dst_nstride = (long long)2 * hl * wl; a.pres = c.fat(sp.flow_up);   // flow = flow_up + residue (spynet.py:65)
@@ -401,8 +405,8 @@ struct WG {   // one weight-gradient launch + reduction
 WgradArgs wg_base(int N, int H, int W) {
     WgradArgs a = {};
     a.N = N; a.H = H; a.W = W; a.nseg = 1;
-    a.x_step = 1; a.Hx = H; a.Wx = W; a.x_nstride = (long long)H * W * C;
-    a.dy_step = 1; a.Hy = H; a.Wy = W; a.dy_nstride = (long long)H * W * C;
+    a.x_step = 1; a.Hx = H; a.Wx = W; a.x_nstride = pm_image_elems(H, W, C);
+    a.dy_step = 1; a.Hy = H; a.Wy = W; a.dy_nstride = pm_image_elems(H, W, C);
     return a;
 }
 
@@ -434,7 +438,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
     for (int z = 0; z < 4; ++z) {
         WgradArgs a = wg_base(n, 2 * h, 2 * w);
         a.x[0] = c.at(p.U0[i]); a.dy[0] = c.at(p.G_U1);
-        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = H4; a.Wy = W4; a.dy_nstride = (long long)H4 * W4 * C;
+        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = H4; a.Wy = W4; a.dy_nstride = pm_image_elems(H4, W4, C);
         CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(1)], C, 0, 4, z, g[ix.up_b(1)]));
     }
     // upsample.0 (at h x w): its input is LeakyReLU(point_conv) => mask with P
@@ -442,7 +446,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
     for (int z = 0; z < 4; ++z) {
         WgradArgs a = wg_base(n, h, w);
         a.x[0] = c.at(p.Pt[i]); a.dy[0] = c.at(p.G_U0);
-        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = 2 * h; a.Wy = 2 * w; a.dy_nstride = (long long)4 * h * w * C;
+        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = 2 * h; a.Wy = 2 * w; a.dy_nstride = pm_image_elems(2 * h, 2 * w, C);
         CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(0)], C, 0, 4, z, g[ix.up_b(0)]));
     }
     {   // point_conv dgrad: two 64-channel outputs (d outputs[i], d feat_prop)
@@ -462,7 +466,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
 // BPTT through one ResidualBlock call; top gradient = dtop (T) + S (fp32 scatter, optional)
 int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, bool add_scatter, bool has_warp) {
     const int n = p.n, h = p.h, w = p.w, rb = p.rb;
-    CK(vsr_launch_add_cast(c.dtype, dtop, add_scatter ? c.fat(p.S) : nullptr, c.at(p.dxoff(dir, i, rb)), (long long)p.px1, c.st));
+    CK(vsr_launch_add_cast(c.dtype, dtop, add_scatter ? c.fat(p.S) : nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
     for (int b = rb - 1; b >= 0; --b) {
         const void* dxn = c.at(p.dxoff(dir, i, b + 1));
         // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
@@ -524,7 +528,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
         CK(recon_backward(c, p, i, lrs, dsr, g));
         CK(trunk_backward(c, p, 1, i, c.at(p.dFF), i < t - 1, i > 0));
         if (i > 0) {   // feat_prop(i) = trunk(warp(feat_prop(i-1), flow_forward[i-1]))
-            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.px1 * 4, st));
+            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.s_elems * 4, st));
             CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp), flow_ptr(c, p, 1, i - 1), (float*)c.at(p.S), n, h, w, C, fstride, st));
         }
     }
@@ -532,7 +536,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     for (int i = 0; i < t; ++i) {
         CK(trunk_backward(c, p, 0, i, c.at(p.dFeatB[i]), i > 0, i < t - 1));
         if (i < t - 1) {   // feat_prop(i) = trunk(warp(feat_prop(i+1), flow_backward[i]))
-            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.px1 * 4, st));
+            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.s_elems * 4, st));
             CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp), flow_ptr(c, p, 0, i), (float*)c.at(p.S), n, h, w, C, fstride, st));
         }
     }
@@ -645,7 +649,7 @@ static CleanPlan clean_plan(int F, int h, int w, int blocks, int dtype) {
     p.blk_w.resize(2 * blocks); p.blk_b.resize(2 * blocks);
     for (int k = 0; k < 2 * blocks; ++k) { p.blk_w[k] = b.take(w64); p.blk_b[k] = b.take(C * 4); }
     p.out_w = b.take((size_t)9 * 32 * C * es); p.out_b = b.take(64 * 4);
-    const size_t a1 = (size_t)F * h * w * C * es;
+    const size_t a1 = (size_t)F * pm_image_elems(h, w, C) * es;
     p.feat = b.take(a1); p.act = b.take(a1);
     p.xa = b.take((size_t)F * 3 * h * w * 4); p.xb = b.take((size_t)F * 3 * h * w * 4);
     p.total = b.off;
@@ -717,7 +721,7 @@ int vsr_pm_to_planar(int dtype, const void* in_pm, float* out, int N, int Cout, 
 static ConvArgs plain64(const void* x, const void* wpack, const float* b, void* y, int N, int H, int W) {
     ConvArgs a = {};
     a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1; a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C;
-    a.dst_nstride = (long long)H * W * C; a.src_nstride[0] = (long long)H * W * C;
+    a.dst_nstride = pm_image_elems(H, W, C); a.src_nstride[0] = pm_image_elems(H, W, C);
     a.src[0] = x; a.wpack = wpack; a.bias = b; a.dst[0] = y;
     return a;
 }

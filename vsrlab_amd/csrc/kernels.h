@@ -13,7 +13,7 @@ int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out,
                         long long flow_nstride, hipStream_t st);
 int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
                         long long flow_nstride, hipStream_t st);
-int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, long long n, hipStream_t st);
+int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, int N, int H, int W, int C, hipStream_t st);
 int vsr_launch_planar_to_pm(int dtype, const float* in, void* out, int N, int Cin, int H, int W, int C, hipStream_t st);
 int vsr_launch_pm_to_planar(int dtype, const void* in, float* out, int N, int Cout, int H, int W, int C, hipStream_t st);
 int vsr_launch_resize_norm(const float* in, float* out, const float* mean, const float* std, int F, int h, int w, int hu,

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                     const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
                     chunk_t v = wzero<T>();
                     if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = ((long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox)) * CX + c * 8;
+                        const long long o = pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c, a.Wx, CX);
                         v = *reinterpret_cast<const chunk_t*>(base + o);
                     }
                     *reinterpret_cast<chunk_t*>(lx + (p * CPX + wswz<CPX>(p, c)) * CHB) = v;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                     const int vy = ty0 + ty, vx = tx0 + tx;
                     chunk_t v = wzero<T>();
                     if (vy < a.H && vx < a.W) {
-                        const long long o = ((long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox)) * COUT + c * 8;
+                        const long long o = pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c, a.Wy, COUT);
                         v = *reinterpret_cast<const chunk_t*>(base + o);
                     }
                     chunk_sum(v, bsum);
@@ -365,11 +365,13 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
             const int idx = piece * 64 + lane;
             const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
             const int ty = p / TWH, tx = p - ty * TWH;
-            rel[i] = (((ty - 1) * a.x_step * a.Wx + (tx - 1) * a.x_step) * 64 + c * 8) * 2;
+            const int dx = (tx - 1) * a.x_step + a.x_ox;        // relative to the segment-aligned origin pm_off(y0, tx0*step)
+            rel[i] = (((((ty - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
         } else {
             const int idx = (piece - DX_PIECES) * 64 + lane;
             const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
-            rel[i] = (((p >> 5) * a.dy_step * a.Wy + (p & 31) * a.dy_step) * 64 + c * 8) * 2;
+            const int dx = (p & 31) * a.dy_step + a.dy_ox;
+            rel[i] = (((((p >> 5) * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
         }
     }
     auto issue = [&](int T, int s) {
@@ -383,8 +385,8 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
         char* lxs = smem + s * DSET;
         const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;      // wave-uniform
         if (interior) {
-            const char* xo = xb + ((long long)(ty0 * a.x_step + a.x_oy) * a.Wx + (tx0 * a.x_step + a.x_ox)) * 128;
-            const char* yo = yb + ((long long)(ty0 * a.dy_step + a.dy_oy) * a.Wy + (tx0 * a.dy_step + a.dy_ox)) * 128;
+            const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, 0, a.Wx, 64) * 2;     // tx0*step: multiple of 32
+            const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, 0, a.Wy, 64) * 2;
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
                 const int piece = wave + 8 * i;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
                 const int ty = p / TWH, tx = p - ty * TWH;
                 const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
                 if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W)
-                    src = xb + (((long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox)) * 64 + c * 8) * 2;
+                    src = xb + pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c, a.Wx, 64) * 2;
                 if (idx < DX_PIX * 8)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(lxs + piece * 1024), 16, 0, 0);
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
                 const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
                 const int vy = ty0 + (p >> 5), vx = tx0 + (p & 31);
                 if (vy < a.H && vx < a.W)
-                    src = yb + (((long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox)) * 64 + c * 8) * 2;
+                    src = yb + pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c, a.Wy, 64) * 2;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lxs + DXB + q * 1024), 16, 0, 0);
             }

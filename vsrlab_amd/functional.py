@@ -62,25 +62,39 @@ def _f32c(x: torch.Tensor) -> torch.Tensor:
 # layout converters (reference planar fp32 <-> library pixel-major)
 # --------------------------------------------------------------------------------------------- #
 def to_pixel_major(x: torch.Tensor, dtype: int, channels: Optional[int] = None) -> torch.Tensor:
-    """(N,C,H,W) fp32 planar -> (N,H,W,Cp) pixel-major in the library's element type."""
+    """(N,C,H,W) fp32 planar -> the library's blocked pixel-major layout
+    (N, H, ceil(W/32), Cp/8, 32, 8) in its element type (csrc/common.h).  The true width rides along as
+    ``.pm_w`` (the padding pixels of the last 32-pixel segment are never read)."""
     _require_gpu(x)
     n, c, h, w = x.shape
     cp = channels or ((c + 15) // 16) * 16
-    out = torch.empty((n, h, w, cp), dtype=_TORCH_DT[dtype], device=x.device)
+    out = torch.empty((n, h, (w + 31) // 32, cp // 8, 32, 8), dtype=_TORCH_DT[dtype], device=x.device)
+    out.pm_w = w
     lib = _lib.load()
     _lib.check(lib.vsr_planar_to_pm(dtype, _ptr(_f32c(x)), _ptr(out), n, c, h, w, cp, _stream()), "planar_to_pm")
     return out
 
 
+def _pm_dims(x: torch.Tensor):
+    n, h, ws, cp8, _, _ = x.shape
+    return n, h, x.pm_w, cp8 * 8
+
+
+def _pm_like(x: torch.Tensor, dtype=None) -> torch.Tensor:
+    out = torch.empty_like(x) if dtype is None else torch.empty(x.shape, dtype=dtype, device=x.device)
+    out.pm_w = x.pm_w
+    return out
+
+
 def from_pixel_major(x: torch.Tensor, channels: Optional[int] = None) -> torch.Tensor:
-    """(N,H,W,Cp) pixel-major -> (N,C,H,W) fp32 planar."""
+    """blocked pixel-major -> (N,C,H,W) fp32 planar."""
     _require_gpu(x)
-    n, h, w, cp = x.shape
+    n, h, w, cp = _pm_dims(x)
     c = channels or cp
     dtype = DT_BF16 if x.dtype == torch.bfloat16 else DT_F32
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.vsr_pm_to_planar(dtype, _ptr(x.contiguous()), _ptr(out), n, c, h, w, cp, _stream()), "pm_to_planar")
+    _lib.check(lib.vsr_pm_to_planar(dtype, _ptr(x), _ptr(out), n, c, h, w, cp, _stream()), "pm_to_planar")
     return out
 
 
@@ -93,8 +107,8 @@ class _FlowWarpFn(torch.autograd.Function):
         n, c, h, w = x.shape
         lib = _lib.load()
         xin = to_pixel_major(x, dtype)
-        cp = xin.shape[-1]
-        out = torch.empty_like(xin)
+        cp = _pm_dims(xin)[3]
+        out = _pm_like(xin)
         flow_planar = _f32c(flow_planar)
         _lib.check(lib.vsr_flow_warp_fwd(dtype, _ptr(xin), _ptr(flow_planar), _ptr(out), n, h, w, cp, _stream()), "flow_warp_fwd")
         ctx.save_for_backward(flow_planar)
@@ -108,9 +122,9 @@ class _FlowWarpFn(torch.autograd.Function):
         n, _, h, w = gout.shape
         lib = _lib.load()
         g = to_pixel_major(gout, dtype, cp)
-        acc = torch.zeros((n, h, w, cp), dtype=torch.float32, device=gout.device)
+        acc = torch.zeros((n, h, w, cp), dtype=torch.float32, device=gout.device)      # plain [N][H][W][C] fp32 accumulator
         _lib.check(lib.vsr_flow_warp_bwd(dtype, _ptr(g), _ptr(flow_planar), _ptr(acc), n, h, w, cp, _stream()), "flow_warp_bwd")
-        return from_pixel_major(acc, c), None, None
+        return acc[..., :c].permute(0, 3, 1, 2).contiguous(), None, None
 
 
 def flow_warp(x: torch.Tensor, flow: torch.Tensor, interpolation: str = "bilinear", padding_mode: str = "zeros",
@@ -132,12 +146,12 @@ def flow_warp(x: torch.Tensor, flow: torch.Tensor, interpolation: str = "bilinea
 def conv3x3_c64(x_pm: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
                 res_pm: Optional[torch.Tensor] = None) -> torch.Tensor:
     _require_gpu(x_pm, weight)
-    n, h, w, c = x_pm.shape
+    n, h, w, c = _pm_dims(x_pm)
     assert c == 64 and tuple(weight.shape) == (64, 64, 3, 3)
     dtype = DT_BF16 if x_pm.dtype == torch.bfloat16 else DT_F32
     lib = _lib.load()
     wpack = torch.empty(9 * 64 * 64, dtype=x_pm.dtype, device=x_pm.device)
-    y = torch.empty_like(x_pm)
+    y = _pm_like(x_pm)
     _lib.check(lib.vsr_conv3x3_c64_fwd(dtype, _ptr(x_pm), _ptr(_f32c(weight)), _ptr(None if bias is None else _f32c(bias)),
                                        _ptr(wpack), _ptr(y), _ptr(res_pm), act, n, h, w, _stream()), "conv3x3_c64_fwd")
     return y
@@ -146,11 +160,11 @@ def conv3x3_c64(x_pm: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
 def conv3x3_c64_dgrad(dy_pm: torch.Tensor, weight: torch.Tensor, res_pm: Optional[torch.Tensor] = None,
                       aux_pm: Optional[torch.Tensor] = None, mask_mode: int = 0) -> torch.Tensor:
     _require_gpu(dy_pm, weight)
-    n, h, w, c = dy_pm.shape
+    n, h, w, c = _pm_dims(dy_pm)
     dtype = DT_BF16 if dy_pm.dtype == torch.bfloat16 else DT_F32
     lib = _lib.load()
     wpack = torch.empty(9 * 64 * 64, dtype=dy_pm.dtype, device=dy_pm.device)
-    dx = torch.empty_like(dy_pm)
+    dx = _pm_like(dy_pm)
     _lib.check(lib.vsr_conv3x3_c64_dgrad(dtype, _ptr(dy_pm), _ptr(_f32c(weight)), _ptr(wpack), _ptr(dx), _ptr(res_pm),
                                          _ptr(aux_pm), mask_mode, n, h, w, _stream()), "conv3x3_c64_dgrad")
     return dx
@@ -158,7 +172,7 @@ def conv3x3_c64_dgrad(dy_pm: torch.Tensor, weight: torch.Tensor, res_pm: Optiona
 
 def conv3x3_c64_wgrad(x_pm: torch.Tensor, dy_pm: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     _require_gpu(x_pm, dy_pm)
-    n, h, w, c = x_pm.shape
+    n, h, w, c = _pm_dims(x_pm)
     dtype = DT_BF16 if x_pm.dtype == torch.bfloat16 else DT_F32
     lib = _lib.load()
     slab = torch.empty(lib.vsr_conv3x3_c64_wgrad_slab_floats(), dtype=torch.float32, device=x_pm.device)
