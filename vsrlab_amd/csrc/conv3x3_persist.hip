@@ -14,10 +14,12 @@
 //   * K loop: 144 v_mfma_f32_32x32x16_bf16 per wave and tile, no barrier inside; A (weights) and B (pixels)
 //     fragments are ds_read_b128 at register base + immediate, issued by hand two k-steps ahead of their
 //     MFMAs (inline asm + counted s_waitcnt: a lone wave per SIMD has nobody to hide an LDS round trip
-//     behind, and hipcc sinks builtin LDS reads back in front of their consumers).  Both LDS images are
-//     [row][8 chunks of 16 B], XOR-swizzled on the chunk (weights by cout row, pixels by x only => a ky
-//     shift is an immediate); the pixel swizzle and the gather out of the blocked global layout are applied
-//     on the DMA's per-lane SOURCE address.  SQ_LDS_BANK_CONFLICT = 0 measured.
+//     behind, and hipcc sinks builtin LDS reads back in front of their consumers).  The weight image is
+//     [cout row][8 chunks of 16 B], XOR-swizzled on the chunk; the pixel image mirrors the blocked global
+//     layout, [tile row][chunk][34 pixels][16 B]: 16 consecutive lanes read 16 consecutive 16-byte slots
+//     (conflict-free without a swizzle), a ky shift is an immediate, and a DMA piece reads runs of up to 512
+//     contiguous bytes (a [pixel][chunk] image made every lane of a piece hit a different line:
+//     +40 % DMA issue time measured).
 //   * epilogue: the accumulator layout (lane = pixel of the segment, registers = 4 consecutive channels) IS
 //     the blocked global layout, so bias / ReLU / LeakyReLU(0.1) / residual add / activation-gradient mask /
 //     pixel-shuffle placement are applied in registers and every store (and residual / mask load) is a wave
@@ -111,19 +113,19 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             breg[cb][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long long)z * a.bias_zstride + cb * 32 + 8 * g + 4 * h)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- DMA pieces of this wave: piece = wave + 4 i.  LDS slot (tile pixel p = (ty,tx), position q) receives
-    // global chunk q ^ ((tx>>1)&7) of that pixel; rel[i] = its source BYTE offset from the tile origin
-    // pm_off(ty0, tx0) in the blocked layout (tx0 is a multiple of 32: one segment per tile row, the halo
-    // columns are the last / first pixel of the neighbouring segments) ----
+    // ---- DMA pieces of this wave: piece = wave + 4 i (64 consecutive 16-byte LDS slots).  rel[i] = the source
+    // BYTE offset of this lane's slot (row ty, chunk c, pixel tx) from the tile origin pm_off(ty0, tx0) in the
+    // blocked layout (tx0 is a multiple of 32: the 32 inner pixels of a row are one global segment, i.e. 512
+    // contiguous bytes per chunk; the halo columns are the last / first pixel of the neighbouring segments) ----
     const char* src = reinterpret_cast<const char*>(a.src[0]);
     const char* zsrc = reinterpret_cast<const char*>(g_conv_zero_chunk);
     int rel[NPIECE_W];
 #pragma unroll
     for (int i = 0; i < NPIECE_W; ++i) {
-        const int idx = (wave + 4 * i) * 64 + lane;
-        const int p = idx >> 3;
-        const int ty = p / PTWH, tx = p - ty * PTWH;
-        const int dx = tx - 1, c = (idx & 7) ^ ((tx >> 1) & 7);
+        const int idx = (wave + 4 * i) * 64 + lane;         // LDS slot = [row ty][chunk c][34 pixels tx] x 16 B
+        const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
+        const int c = rem / PTWH, tx = rem - c * PTWH;
+        const int dx = tx - 1;
         rel[i] = ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
     }
     auto issue = [&](int tile, int buf) {
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             for (int i = 0; i < NPIECE_W; ++i) {
                 const int piece = wave + 4 * i;
                 const int idx = piece * 64 + lane;
-                const int p = idx >> 3;
-                const int ty = p / PTWH, tx = p - ty * PTWH;
+                const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
+                const int tx = rem % PTWH;
                 const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
                 const char* s = (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) ? org + rel[i] : zsrc;
                 if (piece < NPIECE_T && idx < IN_CHUNKS) GLDS16(s, dstb + piece * 1024);
@@ -164,8 +166,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int tx = l31 + kx;
-            b_off[kx][ks] = ((wave * 2 * PTWH + tx) * 8 + ((2 * ks + h) ^ ((tx >> 1) & 7))) * 16;
+            b_off[kx][ks] = wave * 2 * (PTWH * 128) + (2 * ks + h) * (PTWH * 16) + (l31 + kx) * 16;
         }
     // epilogue: lane-constant part of the destination element offset of this lane's 4-channel group, per row:
     // pixel (dy, dx) relative to the tile's destination origin pm_off(ty0*os + ooy, tx0*os) (tx0*os is a multiple of 32)
