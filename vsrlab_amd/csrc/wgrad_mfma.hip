@@ -324,20 +324,27 @@ int launch_wgrad_inst(const WgradArgs& a0, int nwg, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------
 __device__ uint4 g_zero_chunk[2];
 
-constexpr int DX_PIX = (TH + 2) * (TW + 2);          // 340 haloed pixels
-constexpr int DXB = DX_PIX * 128;                    // 43,520
-constexpr int DYB = TH * TW * 128;                   // 32,768
-constexpr int DSET = DXB + DYB;                      // 76,288 per buffer set
-constexpr int DX_PIECES = (DX_PIX * 8 + 63) / 64;    // 43 (the last one half full)
-constexpr int DY_PIECES = TH * TW * 8 / 64;          // 32
+// LDS images mirror the blocked global layout so that a DMA piece reads long contiguous runs:
+//   X  : [10 rows][8 chunks][36 slots of 16 B]  (34 haloed pixels + 2 pad; chunk stride 576 B = 144 banks, so the
+//        4 chunks x 4 pixels x 8 B that a 32-lane half of ds_read_b64_tr_b16 touches fall on 64 distinct banks)
+//   dY : [ 8 rows][8 chunks][35 slots]          (32 pixels + 3 pad; 560 B: two 2-way pairs on the A reads only)
+// 2 x (46,080 + 35,840) B = exactly the 160 KiB of a CU.
+constexpr int XS = 36, YS = 35;                      // slots per chunk row
+constexpr int XROW = 8 * XS * 16, YROW = 8 * YS * 16;   // 4,608 / 4,480 bytes per tile row
+constexpr int DXB = (TH + 2) * XROW;                 // 46,080
+constexpr int DYB = TH * YROW;                       // 35,840
+constexpr int DSET = DXB + DYB;                      // 81,920 per buffer set
+constexpr int DX_SLOTS = (TH + 2) * 8 * XS, DY_SLOTS = TH * 8 * YS;   // 2,880 / 2,240
+constexpr int DX_PIECES = DX_SLOTS / 64;             // 45
+constexpr int DY_PIECES = DY_SLOTS / 64;             // 35
 constexpr int DNT = 512;
+static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
 
 __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int cb = wave & 1, ib = (wave >> 1) & 1, kh = wave >> 2;
-    constexpr int TWH = TW + 2;
 
     f32x16_t acc[9];
 #pragma unroll
@@ -353,25 +360,30 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
     const int total = a.nseg * per_seg;
     const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
 
-    // DMA pieces of this wave: piece = wave + 8 i (43 X pieces, then 32 dY pieces).  rel[i] = this lane's source
-    // byte offset relative to the tile's origin pixel (valid for interior tiles: ~20 VALU per tile instead of
-    // ~40 per piece, which made the first DMA version VALU-bound: 6.8 VALU per MFMA measured).
-    constexpr int NPIECE = (DX_PIECES + DY_PIECES + 7) / 8;       // 10
+    // DMA pieces of this wave: piece = wave + 8 i (45 X pieces, then 35 dY pieces), 64 consecutive LDS slots each.
+    // slot -> (row, chunk, pixel tx); rel[i] = source byte offset from the tile's origin in the blocked layout
+    // (valid for interior tiles; pad slots read the zero word).  pad[i]: this lane's slot is padding.
+    constexpr int NPIECE = (DX_PIECES + DY_PIECES) / 8;           // 10
+    static_assert((DX_PIECES + DY_PIECES) % 8 == 0, "even split over 8 waves");
     int rel[NPIECE];
+    unsigned padmask = 0;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
         const int piece = wave + 8 * i;
         if (piece < DX_PIECES) {
             const int idx = piece * 64 + lane;
-            const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
-            const int ty = p / TWH, tx = p - ty * TWH;
-            const int dx = (tx - 1) * a.x_step + a.x_ox;        // relative to the segment-aligned origin pm_off(y0, tx0*step)
-            rel[i] = (((((ty - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+            const int row = idx / (8 * XS), rem = idx - row * (8 * XS);
+            const int c = rem / XS, tx = rem - c * XS;
+            const int dx = (tx - 1) * a.x_step + a.x_ox;
+            rel[i] = (((((row - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+            if (tx >= TW + 2) padmask |= 1u << i;
         } else {
             const int idx = (piece - DX_PIECES) * 64 + lane;
-            const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
-            const int dx = (p & 31) * a.dy_step + a.dy_ox;
-            rel[i] = (((((p >> 5) * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+            const int row = idx / (8 * YS), rem = idx - row * (8 * YS);
+            const int c = rem / YS, tx = rem - c * YS;
+            const int dx = tx * a.dy_step + a.dy_ox;
+            rel[i] = ((((row * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+            if (tx >= TW) padmask |= 1u << i;
         }
     }
     auto issue = [&](int T, int s) {
@@ -382,47 +394,32 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
         const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
         const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
         const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
+        const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, 0, a.Wx, 64) * 2;      // tx0*step: multiple of 32
+        const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, 0, a.Wy, 64) * 2;
         char* lxs = smem + s * DSET;
-        const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;      // wave-uniform
-        if (interior) {
-            const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, 0, a.Wx, 64) * 2;     // tx0*step: multiple of 32
-            const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, 0, a.Wy, 64) * 2;
+        const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;              // wave-uniform
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) {
-                const int piece = wave + 8 * i;
-                if (piece < DX_PIECES) {
-                    if (piece * 64 + lane < DX_PIX * 8)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xo + rel[i]),
-                                                         (__attribute__((address_space(3))) void*)(lxs + piece * 1024), 16, 0, 0);
-                } else if (piece < DX_PIECES + DY_PIECES) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(yo + rel[i]),
-                                                     (__attribute__((address_space(3))) void*)(lxs + DXB + (piece - DX_PIECES) * 1024), 16, 0, 0);
+        for (int i = 0; i < NPIECE; ++i) {
+            const int piece = wave + 8 * i;
+            const bool isx = piece < DX_PIECES;
+            const char* src = (isx ? xo : yo) + rel[i];
+            bool valid = !((padmask >> i) & 1u);
+            if (!interior && valid) {
+                if (isx) {
+                    const int idx = piece * 64 + lane;
+                    const int row = idx / (8 * XS), tx = (idx - row * (8 * XS)) % XS;
+                    const int vy = ty0 + row - 1, vx = tx0 + tx - 1;
+                    valid = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+                } else {
+                    const int idx = (piece - DX_PIECES) * 64 + lane;
+                    const int row = idx / (8 * YS), tx = (idx - row * (8 * YS)) % YS;
+                    valid = ty0 + row < a.H && tx0 + tx < a.W;
                 }
             }
-            return;
-        }
-        for (int piece = wave; piece < DX_PIECES + DY_PIECES; piece += 8) {     // border tile: per-lane bounds, zero source
-            const char* src = zsrc;
-            if (piece < DX_PIECES) {
-                const int idx = piece * 64 + lane;
-                const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
-                const int ty = p / TWH, tx = p - ty * TWH;
-                const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
-                if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W)
-                    src = xb + pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c, a.Wx, 64) * 2;
-                if (idx < DX_PIX * 8)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(lxs + piece * 1024), 16, 0, 0);
-            } else {
-                const int q = piece - DX_PIECES;
-                const int idx = q * 64 + lane;
-                const int p = idx >> 3, c = (idx & 7) ^ (((p >> 1) & 1) << 2);
-                const int vy = ty0 + (p >> 5), vx = tx0 + (p & 31);
-                if (vy < a.H && vx < a.W)
-                    src = yb + pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c, a.Wy, 64) * 2;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lxs + DXB + q * 1024), 16, 0, 0);
-            }
+            if (!valid) src = zsrc;
+            char* dst = isx ? lxs + piece * 1024 : lxs + DXB + (piece - DX_PIECES) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
@@ -432,15 +429,11 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // transposing-read addresses: lane 4q+p of a 16-lane group supplies row (= pixel) q, columns (= channels) 4p..4p+3
     const int g2 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
     const int chy = cb * 32 + 16 * g2 + p4, chx = ib * 32 + 16 * g2 + p4;
-    const int ybase = (8 * h + q4) * 128 + (((chy >> 3) ^ (((q4 >> 1) & 1) << 2)) << 4) + (chy & 7) * 2;
-    int xbase[2][3];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-            xbase[par][kx] = (8 * h + q4) * 128 + (((chx >> 3) ^ ((par ^ (((kx + q4) >> 1) & 1)) << 2)) << 4) + (chx & 7) * 2;
+    const int ybase = (chy >> 3) * (YS * 16) + (8 * h + q4) * 16 + (chy & 7) * 2;
+    const int xbase = (chx >> 3) * (XS * 16) + (8 * h + q4) * 16 + (chx & 7) * 2;
     for (; T < total; T += gridDim.x) {
         const int next = T + gridDim.x;
         if (next < total) issue(next, cur ^ 1);               // a whole tile ahead of the MFMAs
@@ -450,11 +443,9 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = (tid >> 3) + 64 * i;
-            chunk_sum(*reinterpret_cast<const uint4*>(ly + (p * 8 + ((tid & 7) ^ (((p >> 1) & 1) << 2))) * 16), bsum);
+            chunk_sum(*reinterpret_cast<const uint4*>(ly + (p >> 5) * YROW + (tid & 7) * (YS * 16) + (p & 31) * 16), bsum);
         }
-        // K loop.  All LDS addresses are lane-constant base + wave-uniform row offset + immediate: the swizzle
-        // bit of pixel pix is ((pix >> 1) & 1); with 34- and 32-pixel rows it reduces to
-        //   X : (row parity) ^ (((kx + q4) >> 1) & 1)        dY : ((q4 >> 1) & 1)
+        // K loop.  All LDS addresses are lane-constant base + wave-uniform row offset + immediate
         // (per-read address arithmetic made an earlier version VALU-bound: ~150 VALU per 9 MFMAs).
 #pragma unroll 1
         for (int r2 = 0; r2 < 2; ++r2) {         // 144 accumulators: keep the body small
@@ -463,20 +454,20 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
             // (~130 cycles) is covered by 6 MFMAs instead of being waited for in front of every MFMA.
             typedef union { s16x4_t s[2]; bf16x8_t b; } frag_u;
             frag_u A[2], B[3][3];
-            const char* lyr = ly + ybase + (kh * 4 + r2 * 2) * (TW * 128);
-            const char* lxr = lx + (kh * 4 + r2 * 2) * (TWH * 128);
+            const char* lyr = ly + ybase + (kh * 4 + r2 * 2) * YROW;
+            const char* lxr = lx + xbase + (kh * 4 + r2 * 2) * XROW;
             auto loadA = [&](int ks, frag_u& f) {
-                const char* pa = lyr + (ks >> 1) * (TW * 128) + (ks & 1) * 2048;
+                const char* pa = lyr + (ks >> 1) * YROW + (ks & 1) * 256;
                 f.s[0] = tr_read(pa);
-                f.s[1] = tr_read(pa + 512);
+                f.s[1] = tr_read(pa + 64);
             };
             auto loadB = [&](int g, frag_u* f) {
                 const int ks = g / 3, ky = g - 3 * ks, rr = ks >> 1, half = ks & 1;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const char* pb = lxr + xbase[(rr + ky) & 1][kx] + ((rr + ky) * TWH + half * 16 + kx) * 128;
+                    const char* pb = lxr + (rr + ky) * XROW + (half * 16 + kx) * 16;
                     f[kx].s[0] = tr_read(pb);
-                    f[kx].s[1] = tr_read(pb + 512);
+                    f[kx].s[1] = tr_read(pb + 64);
                 }
             };
             loadA(0, A[0]);
@@ -527,7 +518,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
 }
 
 int launch_wgrad_dma(const WgradArgs& a0, int nslabs, hipStream_t st) {
-    constexpr int LDS = 2 * DSET;                              // 152,576
+    constexpr int LDS = 2 * DSET;                              // 163,840: all of a CU's LDS
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_c64_dma_kernel),
