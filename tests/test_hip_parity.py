@@ -373,3 +373,16 @@ def test_realbasicvsr_inference_vs_golden(dtype):
     assert torch.equal(lrs, keep) and lq.data_ptr() != lrs.data_ptr()
     assert rel_err(lq, g["lq"]) < tol(dtype, 1e-3, 2e-2)
     assert rel_err(sr, g["sr"]) < tol(dtype, 1e-3, 3e-2)
+
+
+def test_long_clip_more_than_8_frames_fp32():
+    """t = 10 > VSR_WG_MAXSEG: the per-layer weight-gradient launches are split over two segment batches and
+    accumulated; odd frame size; fp32 build against the fp32 oracle."""
+    dev = _gpu()
+    shape = (1, 10, 3, 20, 36)
+    m, lrs, cot, sr, grads = _run_basicvsr("fp32", 64, 1, shape, 61, 62, dev)
+    sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 1, 4))
+    sr_o, _, grads_o = O.fwd_bwd(sd, lrs, rand(63, 1, 10, 3, 80, 144), cot=cot)
+    assert rel_err(sr, sr_o) < 1e-3
+    glob, worst, cos = _grad_report(grads, grads_o)
+    assert glob < 2e-3 and worst[0] < 2e-2, (glob, worst)
