@@ -104,6 +104,22 @@ static inline __host__ __device__ long long pm_off(int y, int x, int chunk, int 
     return (((long long)y * pm_ws(W) + seg) * (C >> 3) + chunk) * 256 + (x & 31) * 8;
 }
 
+// XCD-aware work split for persistent kernels: workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an
+// XCD, each with its own 4 MiB L2), so XCD x walks the x-th CONTIGUOUS eighth of the tile list: neighbouring tiles,
+// whose halos overlap, are then served by one L2.  Speed only: any placement computes every tile exactly once.
+struct TileWalk { int first, end, stride; };
+static inline __device__ TileWalk xcd_tile_walk(int total, int block, int nblocks) {
+    TileWalk w;
+    if (nblocks >= 8 && (nblocks & 7) == 0) {
+        const int xcd = block & 7, j = block >> 3;
+        const int lo = (int)((long long)xcd * total / 8), hi = (int)((long long)(xcd + 1) * total / 8);
+        w.first = lo + j; w.end = hi; w.stride = nblocks >> 3;
+    } else {
+        w.first = block; w.end = total; w.stride = nblocks;
+    }
+    return w;
+}
+
 #define HIP_CHECK_RET(expr)                                   \
     do {                                                      \
         hipError_t _e = (expr);                               \

@@ -182,15 +182,16 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     int cur = 0;
-    int tile = blockIdx.x;
-    if (tile < total) issue(tile, 0);
+    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
+    int tile = walk.first;
+    if (tile < walk.end) issue(tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // weights and the first tile are in LDS
 
-    for (; tile < total; tile += gridDim.x) {
+    for (; tile < walk.end; tile += walk.stride) {
         STAMP(t0);
-        const int next = tile + gridDim.x;
-        if (next < total) issue(next, cur ^ 1);            // a whole tile ahead of the MFMAs
+        const int next = tile + walk.stride;
+        if (next < walk.end) issue(next, cur ^ 1);         // a whole tile ahead of the MFMAs
 
         // epilogue operands, requested now, used after the K loop
         int n, ty0, tx0;

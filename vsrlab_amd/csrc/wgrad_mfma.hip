@@ -424,8 +424,9 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
     };
 
     int cur = 0;
-    int T = blockIdx.x;
-    if (T < total) issue(T, 0);
+    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
+    int T = walk.first;
+    if (T < walk.end) issue(T, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -434,9 +435,9 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
     const int chy = cb * 32 + 16 * g2 + p4, chx = ib * 32 + 16 * g2 + p4;
     const int ybase = (chy >> 3) * (YS * 16) + (8 * h + q4) * 16 + (chy & 7) * 2;
     const int xbase = (chx >> 3) * (XS * 16) + (8 * h + q4) * 16 + (chx & 7) * 2;
-    for (; T < total; T += gridDim.x) {
-        const int next = T + gridDim.x;
-        if (next < total) issue(next, cur ^ 1);               // a whole tile ahead of the MFMAs
+    for (; T < walk.end; T += walk.stride) {
+        const int next = T + walk.stride;
+        if (next < walk.end) issue(next, cur ^ 1);            // a whole tile ahead of the MFMAs
         const char* lx = smem + cur * DSET;
         const char* ly = lx + DXB;
         // bias partial sums: this thread's channel chunk (tid & 7) of 4 pixels of the dY tile
