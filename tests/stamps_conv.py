@@ -26,8 +26,9 @@ for res, act, name in ((None, 1, "bias+relu"), (r, 0, "bias+res")):
     out = np.zeros(256 * 8 * 8, dtype=np.uint64)
     assert lib.vsr_debug_read_stamps(out.ctypes.data_as(P)) == 0
     s = out.reshape(256, 8, 8).astype(np.float64)
-    names = ["(unused)", "issue DMA + epilogue operand loads", "K loop", "barrier (tile consumed)", "epilogue", "wait next tile + barrier"]
-    tot = s[:, :4, :6].sum(-1).mean()
-    print(f"[{name}] mean cycles per wave (s_memtime ticks = 100 MHz?): total {tot:.0f}")
-    for k, nm in enumerate(names):
-        print(f"   {nm:26s} mean {s[:, :4, k].mean():10.0f}  min {s[:, :4, k].min():10.0f} max {s[:, :4, k].max():10.0f}  share {s[:, :4, k].mean() / tot:6.1%}")
+    print(f"[{name}] s_memtime ticks (100 MHz), mean over 256 CUs; whole loop incl. prologue wait: {s[:, :, 0].mean():.0f}")
+    for role, waves, slots in (("MFMA waves", slice(0, 4), ((1, "epilogue operand loads"), (2, "K loop"), (3, "epilogue"), (4, "barrier"))),
+                               ("DMA waves", slice(4, 8), ((5, "issue next tile"), (6, "vmcnt(0)"), (7, "barrier")))):
+        for k, nm in slots:
+            v = s[:, waves, k]
+            print(f"   {role:10s} {nm:24s} mean {v.mean():8.0f}  min {v.min():8.0f}  max {v.max():8.0f}")

@@ -29,11 +29,12 @@
 
 namespace {
 
-constexpr int PTW = 32, PTH = 8, PNT = 256;
+constexpr int PTW = 32, PTH = 8, PNT = 512;                              // 4 MFMA waves + 4 DMA waves
 constexpr int PTWH = PTW + 2, PTHH = PTH + 2, PNPIX = PTHH * PTWH;       // 34 x 10 = 340 haloed pixels
 constexpr int W_BYTES = 9 * 64 * 64 * 2;                                  // 73,728
 constexpr int IN_BYTES = PNPIX * 128;                                     // 43,520 per buffer
-constexpr int P_LDS = W_BYTES + 2 * IN_BYTES;                             // 160,768 <= 163,840
+constexpr int BIAS_OFF = W_BYTES + 2 * IN_BYTES;                          // 64 fp32 bias values behind the tiles
+constexpr int P_LDS = BIAS_OFF + 256;                                     // 161,024 <= 163,840
 constexpr int IN_CHUNKS = PNPIX * 8;                                      // 2,720 16-byte chunks
 constexpr int NPIECE_T = (IN_CHUNKS + 63) / 64;                           // 43 DMA pieces of 1 KiB (last half full)
 constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11 per wave
@@ -85,8 +86,13 @@ template <int ACT, bool HAS_RES, int MASK>
 __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2);            // 0: MFMA + epilogue, 1: LDS-DMA producer
+    const int w4 = wave & 3;                                               // index within the role
     const int l31 = lane & 31, h = lane >> 5;
     char* lds_w = smem;
+#ifdef VSR_STAMPS
+    const unsigned long long st_begin = stamp();
+#endif
     char* lds_t = smem + W_BYTES;                                         // two tile buffers
 
     const int z = blockIdx.y;
@@ -94,24 +100,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     const int total = a.N * ntx * nty;
     const int WSs = pm_ws(a.W), WSd = pm_ws(a.Wd);
 
-    // ---- weights of this z: global [tap][cout][cin] -> LDS, chunk c of row r at (r*8 + (c ^ ((r>>1)&7))) ----
-    {
-        const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.wpack) + (long long)z * a.w_zstride);
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int idx = tid + i * PNT;                 // 4608 chunks
-            const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;
-            *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[idx];
-        }
-    }
-    // this lane's 32 bias values in accumulator layout (couts cb*32 + 8g + 4h + j)
-    float4 breg[2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            breg[cb][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long long)z * a.bias_zstride + cb * 32 + 8 * g + 4 * h)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    // bias of this z as fp32 in LDS: the accumulators of every tile start from it (32 fewer live registers
+    // than carrying it, which is what lets two waves share a SIMD)
+    if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = a.bias ? a.bias[(long long)z * a.bias_zstride + tid] : 0.f;
 
     // ---- DMA pieces of this wave: piece = wave + 4 i (64 consecutive 16-byte LDS slots).  rel[i] = the source
     // BYTE offset of this lane's slot (row ty, chunk c, pixel tx) from the tile origin pm_off(ty0, tx0) in the
@@ -122,7 +113,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     int rel[NPIECE_W];
 #pragma unroll
     for (int i = 0; i < NPIECE_W; ++i) {
-        const int idx = (wave + 4 * i) * 64 + lane;         // LDS slot = [row ty][chunk c][34 pixels tx] x 16 B
+        const int idx = (w4 + 4 * i) * 64 + lane;           // LDS slot = [row ty][chunk c][34 pixels tx] x 16 B
         const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
         const int c = rem / PTWH, tx = rem - c * PTWH;
         const int dx = tx - 1;
@@ -136,13 +127,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         if (ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W) {          // interior tile (wave-uniform)
 #pragma unroll
             for (int i = 0; i < NPIECE_W; ++i) {
-                const int piece = wave + 4 * i;
+                const int piece = w4 + 4 * i;
                 if (piece < NPIECE_T && piece * 64 + lane < IN_CHUNKS) GLDS16(org + rel[i], dstb + piece * 1024);
             }
         } else {                                                                    // border: bounds per lane, zero source
 #pragma unroll
             for (int i = 0; i < NPIECE_W; ++i) {
-                const int piece = wave + 4 * i;
+                const int piece = w4 + 4 * i;
                 const int idx = piece * 64 + lane;
                 const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
                 const int tx = rem % PTWH;
@@ -153,21 +144,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         }
     };
 
-    // fragment base addresses (bytes): A per (cb, ks), B per (kx, ks); taps / rows are immediates
-    int a_off[2][4], b_off[3][4];
+    // fragment base addresses (bytes).  A: one per ks (the XOR swizzle is not additive in ks; cb and the tap are
+    // immediates: the swizzle key ((r >> 1) & 7) is the same for rows r and r + 32).  B: ONE lane base; tile row,
+    // ky, kx and ks are all immediates of the [row][chunk][34 px][16 B] image.
+    int a_off[4];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int r = cb * 32 + l31;
-            a_off[cb][ks] = (r * 8 + ((2 * ks + h) ^ ((r >> 1) & 7))) * 16;
-        }
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            b_off[kx][ks] = wave * 2 * (PTWH * 128) + (2 * ks + h) * (PTWH * 16) + (l31 + kx) * 16;
-        }
+    for (int ks = 0; ks < 4; ++ks) a_off[ks] = (l31 * 8 + ((2 * ks + h) ^ ((l31 >> 1) & 7))) * 16;
+    const int b_lane = w4 * 2 * (PTWH * 128) + h * (PTWH * 16) + l31 * 16;
     // epilogue: lane-constant part of the destination element offset of this lane's 4-channel group, per row:
     // pixel (dy, dx) relative to the tile's destination origin pm_off(ty0*os + ooy, tx0*os) (tx0*os is a multiple of 32)
     int loff[2];
@@ -175,7 +158,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         const int dx = l31 * a.out_step + a.out_ox[z];
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw)
-            loff[rw] = ((((wave * 2 + rw) * a.out_step) * WSd + (dx >> 5)) * 8) * 256 + (dx & 31) * 8 + 4 * h;
+            loff[rw] = ((((w4 * 2 + rw) * a.out_step) * WSd + (dx >> 5)) * 8) * 256 + (dx & 31) * 8 + 4 * h;
     }
 
 #ifdef VSR_STAMPS
@@ -184,14 +167,36 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     int cur = 0;
     const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
     int tile = walk.first;
-    if (tile < walk.end) issue(tile, 0);
+    if (role == 1 && tile < walk.end) issue(tile, 0);      // first tile in flight while the weights are staged
+    // ---- weights of this z: global [tap][cout][cin] -> LDS, chunk c of row r at (r*8 + (c ^ ((r>>1)&7))) ----
+    {
+        const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.wpack) + (long long)z * a.w_zstride);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int idx = tid + i * PNT;                 // 4608 chunks
+            const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;
+            *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[idx];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // weights and the first tile are in LDS
 
     for (; tile < walk.end; tile += walk.stride) {
         STAMP(t0);
         const int next = tile + walk.stride;
-        if (next < walk.end) issue(next, cur ^ 1);         // a whole tile ahead of the MFMAs
+        if (role == 1) {
+            // ---- producer waves: fill the other buffer with the next tile while the MFMA waves work on this one.
+            // Their VMEM issue slots run beside the MFMA waves' matrix-core time on the same SIMD. ----
+            if (next < walk.end) issue(next, cur ^ 1);
+            STAMP(p1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(p2);
+            __syncthreads();
+            STAMP(p3);
+            STAMP_ADD(5, t0, p1); STAMP_ADD(6, p1, p2); STAMP_ADD(7, p2, p3);
+            cur ^= 1;
+            continue;
+        }
 
         // epilogue operands, requested now, used after the K loop
         int n, ty0, tx0;
@@ -199,10 +204,11 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oy[z], tx0 * a.out_step, 0, a.Wd, 64);
         const bool okx = tx0 + l31 < a.W;
         bool ok[2];
+        constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE;   // both operands early would not fit 2 waves / SIMD
         bf4 rr[2][2][4], mm[2][2][4];
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
-            ok[rw] = okx && (ty0 + wave * 2 + rw < a.H);
+            ok[rw] = okx && (ty0 + w4 * 2 + rw < a.H);
             if (ok[rw]) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     for (int g = 0; g < 4; ++g) {
                         const long long o = tbase + loff[rw] + (cb * 4 + g) * 256;
                         if (HAS_RES) rr[rw][cb][g] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + o);
-                        if (MASK != MASK_NONE) mm[rw][cb][g] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
+                        if (MASK != MASK_NONE && !LATE_MASK) mm[rw][cb][g] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
                     }
             }
         }
@@ -223,29 +229,33 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             for (int rw = 0; rw < 2; ++rw)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[cb][rw][i] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                   // couts cb*32 + 8g + 4h + j
+                const float4 bv = *reinterpret_cast<const float4*>(smem + BIAS_OFF + (cb * 32 + 8 * g + 4 * h) * 4);
+                acc[cb][0][4 * g + 0] = bv.x; acc[cb][0][4 * g + 1] = bv.y; acc[cb][0][4 * g + 2] = bv.z; acc[cb][0][4 * g + 3] = bv.w;
+                acc[cb][1][4 * g + 0] = bv.x; acc[cb][1][4 * g + 1] = bv.y; acc[cb][1][4 * g + 2] = bv.z; acc[cb][1][4 * g + 3] = bv.w;
+            }
 
         // ---- K loop: 36 steps s = (tap, ks) of 4 MFMAs.  The 4 fragment reads of step s+2 are issued before
         // the MFMAs of step s, by hand: lgkmcnt(8) = "all but the 8 youngest LDS reads have returned" = step s
         // is in registers. ----
         bf16x8_t fa[3][2], fb[3][2];
-        unsigned bb[3][4];                                   // B base addresses of this tile's buffer
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bb[kx][ks] = (unsigned)(W_BYTES + cur * IN_BYTES + b_off[kx][ks]);
+        const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);   // B base of this tile's buffer
 #define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 #define CV_LOAD(s, slot)                                                                                               \
         {                                                                                                              \
             constexpr int tap_ = (s) / 4, ks_ = (s) % 4, ky_ = tap_ / 3, kx_ = tap_ % 3;                               \
             if (tap_ < 8) {                                                                                            \
-                DSR(fa[slot][0], (unsigned)a_off[0][ks_], tap_ < 8 ? tap_ * 8192 : 0);                                 \
-                DSR(fa[slot][1], (unsigned)a_off[1][ks_], tap_ < 8 ? tap_ * 8192 : 0);                                 \
+                DSR(fa[slot][0], (unsigned)a_off[ks_], tap_ < 8 ? tap_ * 8192 : 0);                                    \
+                DSR(fa[slot][1], (unsigned)a_off[ks_], tap_ < 8 ? tap_ * 8192 + 4096 : 0);                             \
             } else {                                                                                                   \
-                DSR(fa[slot][0], (unsigned)a_off[0][ks_] + 8192u, 57344);                                              \
-                DSR(fa[slot][1], (unsigned)a_off[1][ks_] + 8192u, 57344);                                              \
+                DSR(fa[slot][0], (unsigned)a_off[ks_] + 8192u, 57344);                                                 \
+                DSR(fa[slot][1], (unsigned)a_off[ks_] + 8192u, 57344 + 4096);                                          \
             }                                                                                                          \
-            DSR(fb[slot][0], bb[kx_][ks_], ky_ * (PTWH * 128));                                                        \
-            DSR(fb[slot][1], bb[kx_][ks_], (1 + ky_) * (PTWH * 128));                                                  \
+            DSR(fb[slot][0], bb, ky_ * (PTWH * 128) + ks_ * (PTWH * 32) + kx_ * 16);                                   \
+            DSR(fb[slot][1], bb, (1 + ky_) * (PTWH * 128) + ks_ * (PTWH * 32) + kx_ * 16);                             \
         }
 #define CV_STEP(s)                                                                                                     \
         {                                                                                                              \
@@ -283,16 +293,18 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float v[4];
-                        v[0] = p_act<ACT>(acc[cb][rw][4 * g + 0] + breg[cb][g].x); v[1] = p_act<ACT>(acc[cb][rw][4 * g + 1] + breg[cb][g].y);
-                        v[2] = p_act<ACT>(acc[cb][rw][4 * g + 2] + breg[cb][g].z); v[3] = p_act<ACT>(acc[cb][rw][4 * g + 3] + breg[cb][g].w);
+                        v[0] = p_act<ACT>(acc[cb][rw][4 * g + 0]); v[1] = p_act<ACT>(acc[cb][rw][4 * g + 1]);
+                        v[2] = p_act<ACT>(acc[cb][rw][4 * g + 2]); v[3] = p_act<ACT>(acc[cb][rw][4 * g + 3]);
                         if (HAS_RES) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += (float)rr[rw][cb][g].v[j];
                         }
                         if (MASK != MASK_NONE) {
                             constexpr float neg = MASK == MASK_LEAKY ? 0.1f : 0.f;
+                            const bf4 mv = LATE_MASK ? *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[rw] + (cb * 4 + g) * 256)
+                                                     : mm[rw][cb][g];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mm[rw][cb][g].v[j] > 0.f ? 1.f : neg);
+                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mv.v[j] > 0.f ? 1.f : neg);
                         }
                         bf4 o;
 #pragma unroll
@@ -302,13 +314,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             }
         }
         STAMP(t3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (this wave's pieces)
-        __syncthreads();                                      // ... everybody's; and everybody has finished reading `cur`
+        __syncthreads();                                      // the producers' next tile has landed; everybody has finished reading `cur`
         cur ^= 1;
         STAMP(t4);
         STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
     }
 #ifdef VSR_STAMPS
+    st_sum[0] = stamp() - st_begin;
     if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
         for (int k = 0; k < 8; ++k) g_stamps[(blockIdx.x * 8 + wave) * 8 + k] = st_sum[k];
 #endif

@@ -75,13 +75,14 @@ struct Plan {
     // trunk activations: [dir][frame]
     std::vector<size_t> Wp[2], X[2], A[2];      // X: (rb+1) per frame, A: rb per frame (saved mode)
     std::vector<size_t> feat[2];                // = X[rb]
-    size_t scratchA, scratchW;                  // inference mode
+    size_t scratchA[2], scratchW[2];            // inference mode, per direction (the directions run concurrently)
     // reconstruction
     std::vector<size_t> Pt, U0, U1, C0;
     // backward
     std::vector<size_t> G0[2], G1[2], DX[2];    // G1: rb per frame, DX: (rb+1) per frame (DX[0] unused -> G0)
-    std::vector<size_t> dFeatB;
-    size_t dFF, S, dWp, G_C0, G_U1, G_U0, G_P, slab;
+    std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
+    size_t S[2], dWp[2], slab[2];               // per direction / stream
+    size_t G_C0, G_U1, G_U0, G_P;
     size_t total;
 
     size_t xoff(int dir, int i, int b) const { return X[dir][(size_t)i * (rb + 1) + b]; }
@@ -128,7 +129,7 @@ struct Plan {
                 for (int i = 0; i < t; ++i) feat[dir][i] = b.take(a1);
             }
         }
-        scratchA = b.take(a1); scratchW = b.take(a1);
+        for (int dir = 0; dir < 2; ++dir) { scratchA[dir] = b.take(a1); scratchW[dir] = b.take(a1); }
         const int nrec = bwd ? t : 1;
         Pt.assign(t, 0); U0.assign(t, 0); U1.assign(t, 0); C0.assign(t, 0);
         for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
@@ -142,13 +143,13 @@ struct Plan {
                     for (int k = 1; k <= rb; ++k) DX[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
                 }
             }
-            dFeatB.assign(t, 0);
-            for (int i = 0; i < t; ++i) dFeatB[i] = b.take(a1);
-            dFF = b.take(a1); S = b.take(s_elems * 4); dWp = b.take(a1);
+            dFeatB.assign(t, 0); dFF.assign(t, 0);
+            for (int i = 0; i < t; ++i) { dFeatB[i] = b.take(a1); dFF[i] = b.take(a1); }
+            for (int dir = 0; dir < 2; ++dir) { S[dir] = b.take(s_elems * 4); dWp[dir] = b.take(a1); }
             G_C0 = b.take(a4); G_U1 = b.take(a4); G_U0 = b.take(a2); G_P = b.take(a1);
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
-            slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+            for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
         }
         total = b.off;
         return VSR_OK;
@@ -162,6 +163,7 @@ struct Ctx {
     char* ws;
     hipStream_t st;
     int dtype;
+    int lane;                   // 0: the caller's stream, 1: the helper stream (selects per-stream scratch)
     void* at(size_t off) const { return ws + off; }
     const float* fat(size_t off) const { return reinterpret_cast<const float*>(ws + off); }
 
@@ -322,7 +324,7 @@ int trunk_forward(const Ctx& c, const Plan& p, int dir, int i, const void* warpe
         CK(vsr_launch_conv(c.dtype, 3, 2, 64, 16, 1, 64, EPI_NHWC, a, c.st));
     }
     for (int b = 0; b < rb; ++b) {      // x + conv2(relu(conv1(x)))   (conv.py:89-92)
-        void* act = p.bwd ? c.at(p.aoff(dir, i, b)) : c.at(p.scratchA);
+        void* act = p.bwd ? c.at(p.aoff(dir, i, b)) : c.at(p.scratchA[dir]);
         void* xn = p.bwd ? c.at(p.xoff(dir, i, b + 1)) : x;   // inference: in place (residual read = own pixel)
         CK(c.conv64(x, p.blk_w[dir][2 * b], c.fat(p.blk_b[dir][2 * b]), act, ACT_RELU, nullptr, nullptr, 0, n, h, w));
         CK(c.conv64(act, p.blk_w[dir][2 * b + 1], c.fat(p.blk_b[dir][2 * b + 1]), xn, ACT_NONE, x, nullptr, 0, n, h, w));
@@ -356,32 +358,83 @@ const float* flow_ptr(const Ctx& c, const Plan& p, int forward, int i) {   // fl
     return c.fat(p.flows) + ((size_t)forward * p.n * (p.t - 1) + i) * 2 * p.h * p.w;
 }
 
-int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float* sr, char* ws, hipStream_t st) {
-    const Ctx c{p, ws, st, p.dtype};
-    const PIdx ix{p.rb};
+// The two propagation directions are independent until the fusion conv (basicvsr.py:46-77), so their
+// chains of 61 dependent launches per frame run on two streams: each stream's launch gap and pipeline
+// fill is covered by the other's kernels.  The helper stream is forked from and joined to the caller's
+// stream with events, so for the caller all work is still ordered in the stream it passed.
+struct Helper { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int dev = -1; };
+int get_helper(Helper** out) {
+    thread_local Helper hp[16];
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return VSR_ERR_UNSUPPORTED;
+    Helper& x = hp[dev];
+    if (!x.s) {
+        HIP_CHECK_RET(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
+        HIP_CHECK_RET(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
+        HIP_CHECK_RET(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
+        x.dev = dev;
+    }
+    *out = &x;
+    return VSR_OK;
+}
+bool single_stream() {
+    static const bool v = [] { const char* e = getenv("VSRLAB_AMD_SINGLE_STREAM"); return e && e[0] == '1'; }();
+    return v;
+}
+struct Fork {   // RAII: the join is enqueued on every exit path
+    hipStream_t main; Helper* h; bool active = false;
+    int begin() {
+        if (single_stream()) return VSR_OK;
+        CK(get_helper(&h));
+        HIP_CHECK_RET(hipEventRecord(h->fork, main));
+        HIP_CHECK_RET(hipStreamWaitEvent(h->s, h->fork, 0));
+        active = true;
+        return VSR_OK;
+    }
+    hipStream_t side() const { return active ? h->s : main; }
+    int end() {
+        if (!active) return VSR_OK;
+        active = false;
+        HIP_CHECK_RET(hipEventRecord(h->join, h->s));
+        HIP_CHECK_RET(hipStreamWaitEvent(main, h->join, 0));
+        return VSR_OK;
+    }
+    ~Fork() { (void)end(); }
+};
+
+int forward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs) {
     const int n = p.n, t = p.t, h = p.h, w = p.w;
     const long long fstride = (long long)(t - 1) * 2 * h * w;
+    for (int k = 0; k < t; ++k) {
+        // dir 0: backward-time propagation, frames t-1 .. 0 (basicvsr.py:46-60); dir 1: forward-time (basicvsr.py:62-73)
+        const int i = dir == 0 ? t - 1 - k : k;
+        void* warped = nullptr;
+        if (k > 0) {
+            const int prev = dir == 0 ? i + 1 : i - 1;
+            warped = p.bwd ? c.at(p.Wp[dir][i]) : c.at(p.scratchW[dir]);
+            CK(vsr_launch_warp_fwd(c.dtype, c.at(p.feat[dir][prev]), flow_ptr(c, p, dir, dir == 0 ? i : i - 1), warped, n, h, w, C, fstride, c.st));
+        }
+        CK(trunk_forward(c, p, dir, i, warped, lrs));
+    }
+    return VSR_OK;
+}
+
+int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float* sr, char* ws, hipStream_t st) {
+    const Ctx c{p, ws, st, p.dtype, 0};
+    const PIdx ix{p.rb};
+    const int n = p.n, t = p.t;
     CK(pack_all(c, p, prm));
     if (t > 1) CK(spynet_run(c, p.spy, lrs, prm[ix.spy_mean()], prm[ix.spy_std()], n, t, 0, (float*)c.at(p.flows)));
-    // backward-time propagation (basicvsr.py:46-60)
-    for (int i = t - 1; i >= 0; --i) {
-        void* warped = nullptr;
-        if (i < t - 1) {
-            warped = p.bwd ? c.at(p.Wp[0][i]) : c.at(p.scratchW);
-            CK(vsr_launch_warp_fwd(c.dtype, c.at(p.feat[0][i + 1]), flow_ptr(c, p, 0, i), warped, n, h, w, C, fstride, st));
-        }
-        CK(trunk_forward(c, p, 0, i, warped, lrs));
+    {
+        Fork f{st, nullptr};
+        CK(f.begin());
+        const Ctx c1{p, ws, f.side(), p.dtype, 1};
+        CK(forward_chain(c, p, 0, lrs));
+        CK(forward_chain(c1, p, 1, lrs));
+        CK(f.end());
     }
-    // forward-time propagation + reconstruction (basicvsr.py:62-82)
-    for (int i = 0; i < t; ++i) {
-        void* warped = nullptr;
-        if (i > 0) {
-            warped = p.bwd ? c.at(p.Wp[1][i]) : c.at(p.scratchW);
-            CK(vsr_launch_warp_fwd(c.dtype, c.at(p.feat[1][i - 1]), flow_ptr(c, p, 1, i - 1), warped, n, h, w, C, fstride, st));
-        }
-        CK(trunk_forward(c, p, 1, i, warped, lrs));
-        CK(recon_forward(c, p, i, lrs, sr));
-    }
+    for (int i = 0; i < t; ++i) CK(recon_forward(c, p, i, lrs, sr));      // fusion + upsampling (basicvsr.py:75-82)
     return VSR_OK;
 }
 
@@ -393,7 +446,7 @@ struct WG {   // one weight-gradient launch + reduction
         if (!gw && !gb) return VSR_OK;
         int cp, xpd, stride;
         vsr_wgrad_slab_dims(ks, cx, cout, &cp, &xpd, &stride);
-        a.slab = (float*)c.at(c.p.slab); a.slab_stride = stride;
+        a.slab = (float*)c.at(c.p.slab[c.lane]); a.slab_stride = stride;
         const int tiles = a.N * cdiv(a.H, 8) * cdiv(a.W, 32);
         const int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
         CK(vsr_launch_wgrad(c.dtype, ks, cx, xp, cout, dyp, a, nwg, c.st));
@@ -452,7 +505,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
     {   // point_conv dgrad: two 64-channel outputs (d outputs[i], d feat_prop)
         ConvArgs a = c.base(n, h, w);
         a.src[0] = c.at(p.G_P); a.wpack = c.at(p.point_wd); a.w_zstride = C * C; a.nz = 2;
-        a.dst[0] = c.at(p.dFeatB[i]); a.dst[1] = c.at(p.dFF);
+        a.dst[0] = c.at(p.dFeatB[i]); a.dst[1] = c.at(p.dFF[i]);
         CK(vsr_launch_conv(c.dtype, 1, 1, 64, 64, 0, 64, EPI_NHWC, a, c.st));
     }
     for (int s = 0; s < 2; ++s) {
@@ -466,7 +519,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
 // BPTT through one ResidualBlock call; top gradient = dtop (T) + S (fp32 scatter, optional)
 int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, bool add_scatter, bool has_warp) {
     const int n = p.n, h = p.h, w = p.w, rb = p.rb;
-    CK(vsr_launch_add_cast(c.dtype, dtop, add_scatter ? c.fat(p.S) : nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
+    CK(vsr_launch_add_cast(c.dtype, dtop, add_scatter ? c.fat(p.S[dir]) : nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
     for (int b = rb - 1; b >= 0; --b) {
         const void* dxn = c.at(p.dxoff(dir, i, b + 1));
         // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
@@ -477,7 +530,7 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
                     b == 0 ? MASK_LEAKY : 0, n, h, w));
     }
     if (has_warp)   // gradient w.r.t. the warped state (feat part of the stem's input)
-        CK(c.conv64(c.at(p.G0[dir][i]), p.stem_wd[dir], nullptr, c.at(p.dWp), ACT_NONE, nullptr, nullptr, 0, n, h, w));
+        CK(c.conv64(c.at(p.G0[dir][i]), p.stem_wd[dir], nullptr, c.at(p.dWp[dir]), ACT_NONE, nullptr, nullptr, 0, n, h, w));
     return VSR_OK;
 }
 
@@ -517,31 +570,35 @@ int trunk_wgrads(const Ctx& c, const Plan& p, int dir, const float* lrs, float* 
     return VSR_OK;
 }
 
+// BPTT through one direction's chain, then that direction's weight gradients (all frames per launch)
+int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float* const* g) {
+    const int n = p.n, t = p.t, h = p.h, w = p.w;
+    const long long fstride = (long long)(t - 1) * 2 * h * w;
+    for (int k = 0; k < t; ++k) {
+        // the state of dir 1 flows 0 -> t-1, so its gradient flows t-1 -> 0; dir 0 the other way round
+        const int i = dir == 1 ? t - 1 - k : k;
+        const void* dtop = dir == 1 ? c.at(p.dFF[i]) : c.at(p.dFeatB[i]);
+        const bool last = k == t - 1;                     // the chain's first frame had no warped state
+        CK(trunk_backward(c, p, dir, i, dtop, k > 0, !last));
+        if (!last) {   // feat(i) = trunk(warp(feat(prev), flow)): scatter the gradient of the warped state back
+            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S[dir]), 0, p.s_elems * 4, c.st));
+            CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp[dir]), flow_ptr(c, p, dir, dir == 1 ? i - 1 : i), (float*)c.at(p.S[dir]), n, h, w, C, fstride, c.st));
+        }
+    }
+    return trunk_wgrads(c, p, dir, lrs, g);
+}
+
 int backward_impl(const Plan& p, const float* const* prm, float* const* g, const float* lrs, const float* dsr, char* ws,
                   hipStream_t st) {
     (void)prm;
-    const Ctx c{p, ws, st, p.dtype};
-    const int n = p.n, t = p.t, h = p.h, w = p.w;
-    const long long fstride = (long long)(t - 1) * 2 * h * w;
-    // reconstruction + forward-time trunk, last frame first
-    for (int i = t - 1; i >= 0; --i) {
-        CK(recon_backward(c, p, i, lrs, dsr, g));
-        CK(trunk_backward(c, p, 1, i, c.at(p.dFF), i < t - 1, i > 0));
-        if (i > 0) {   // feat_prop(i) = trunk(warp(feat_prop(i-1), flow_forward[i-1]))
-            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.s_elems * 4, st));
-            CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp), flow_ptr(c, p, 1, i - 1), (float*)c.at(p.S), n, h, w, C, fstride, st));
-        }
-    }
-    // backward-time trunk: state flows t-1 -> 0, so its gradient flows 0 -> t-1
-    for (int i = 0; i < t; ++i) {
-        CK(trunk_backward(c, p, 0, i, c.at(p.dFeatB[i]), i > 0, i < t - 1));
-        if (i < t - 1) {   // feat_prop(i) = trunk(warp(feat_prop(i+1), flow_backward[i]))
-            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S), 0, p.s_elems * 4, st));
-            CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp), flow_ptr(c, p, 0, i), (float*)c.at(p.S), n, h, w, C, fstride, st));
-        }
-    }
-    for (int dir = 0; dir < 2; ++dir) CK(trunk_wgrads(c, p, dir, lrs, g));
-    return VSR_OK;
+    const Ctx c{p, ws, st, p.dtype, 0};
+    for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g));   // -> dFeatB[i], dFF[i]
+    Fork f{st, nullptr};
+    CK(f.begin());
+    const Ctx c1{p, ws, f.side(), p.dtype, 1};
+    CK(backward_chain(c, p, 1, lrs, g));
+    CK(backward_chain(c1, p, 0, lrs, g));
+    return f.end();
 }
 
 }  // namespace
