@@ -340,6 +340,23 @@ constexpr int DY_PIECES = DY_SLOTS / 64;             // 35
 constexpr int DNT = 512;
 static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
 
+// Diagnostic build only (make STAMPS=1): per-wave cycle sums of the phases of a tile, to a buffer of their own.
+#ifdef VSR_STAMPS
+__device__ unsigned long long g_wg_stamps[256 * 8 * 8];
+__device__ __forceinline__ unsigned long long wstamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define WSTAMP(var) const unsigned long long var = wstamp()
+#define WSTAMP_ADD(slot, a, b) wst[slot] += (b) - (a)
+#else
+#define WSTAMP(var)
+#define WSTAMP_ADD(slot, a, b)
+#endif
+
 __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,6 +440,10 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
         }
     };
 
+#ifdef VSR_STAMPS
+    unsigned long long wst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long wbegin = wstamp();
+#endif
     int cur = 0;
     const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
     int T = walk.first;
@@ -437,7 +458,14 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
     const int xbase = (chx >> 3) * (XS * 16) + (8 * h + q4) * 16 + (chx & 7) * 2;
     for (; T < walk.end; T += walk.stride) {
         const int next = T + walk.stride;
-        if (next < walk.end) issue(next, cur ^ 1);            // a whole tile ahead of the MFMAs
+        WSTAMP(w0);
+        // Requested a tile ahead, but NOT overlapped with this tile's K loop: hipcc assumes the LDS-DMA may alias
+        // the LDS reads below and waits for it (s_waitcnt vmcnt(0)) in front of the first of them, and the variants
+        // that do overlap (inline-asm DMA in one burst; pieces spread through the K loop; staggered bursts)
+        // all measured SLOWER, 85-134 us against 76 us per frame: an LDS-DMA piece issued beside the K loop's
+        // ds_read stream sits ~1.2 k cycles in the memory pipe instead of ~0.5 k (in-kernel stamps).
+        if (next < walk.end) issue(next, cur ^ 1);
+        WSTAMP(w1);
         const char* lx = smem + cur * DSET;
         const char* ly = lx + DXB;
         // bias partial sums: this thread's channel chunk (tid & 7) of 4 pixels of the dY tile
@@ -446,6 +474,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
             const int p = (tid >> 3) + 64 * i;
             chunk_sum(*reinterpret_cast<const uint4*>(ly + (p >> 5) * YROW + (tid & 7) * (YS * 16) + (p & 31) * 16), bsum);
         }
+        WSTAMP(w2);
         // K loop.  All LDS addresses are lane-constant base + wave-uniform row offset + immediate
         // (per-read address arithmetic made an earlier version VALU-bound: ~150 VALU per 9 MFMAs).
 #pragma unroll 1
@@ -491,10 +520,19 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
             WG_GROUP(6) WG_GROUP(7) WG_GROUP(8) WG_GROUP(9) WG_GROUP(10) WG_GROUP(11)
 #undef WG_GROUP
         }
+        WSTAMP(w3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile has landed (this wave's pieces)
+        WSTAMP(w4);
         __syncthreads();                                       // ... everybody's; and `cur` is free again
+        WSTAMP(w5);
+        WSTAMP_ADD(1, w0, w1); WSTAMP_ADD(2, w1, w2); WSTAMP_ADD(3, w2, w3); WSTAMP_ADD(4, w3, w4); WSTAMP_ADD(5, w4, w5);
         cur ^= 1;
     }
+#ifdef VSR_STAMPS
+    wst[0] = wstamp() - wbegin;
+    if (lane == 0 && blockIdx.x < 256)
+        for (int k = 0; k < 8; ++k) g_wg_stamps[(blockIdx.x * 8 + wave) * 8 + k] = wst[k];
+#endif
 
     // ---- partial slabs: one per (workgroup, row-half): [tap][64][64] then [64] bias sums ----
     float* slab = a.slab + (long long)(blockIdx.x * 2 + kh) * a.slab_stride;
@@ -535,6 +573,12 @@ int launch_wgrad_dma(const WgradArgs& a0, int nslabs, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef VSR_STAMPS
+extern "C" int vsr_debug_read_wgrad_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 #define VSR_WGRAD_SHAPES(X)           \
     X(3, 64, false, 64, false)        /* trunk / upsample / conv_last.0 */ \
