@@ -58,7 +58,9 @@ typedef struct VsrBasicVSRDesc {
 int vsr_basicvsr_num_params(const VsrBasicVSRDesc* d);
 
 /* Bytes of workspace the caller must provide (same buffer for forward and its backward).
- * need_backward = 0: inference (activations are not retained).                              */
+ * need_backward = 0: inference (activations are not retained); 1: training with the flow net
+ * frozen (train_flow=False, basicvsr.py:25-28); 2: training incl. SPyNet (train_flow=True:
+ * SPyNet's activations are retained too).                                                    */
 size_t vsr_basicvsr_workspace_bytes(const VsrBasicVSRDesc* d, int need_backward);
 
 /* sr = BasicVSR(lrs).  `params`: HOST array of num_params device pointers.                   */
@@ -67,8 +69,10 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
                          int need_backward, void* stream);
 
 /* Back-propagates dsr (n,t,3,4h,4w) through the forward that last ran on `workspace`
- * (need_backward=1).  grads[k] (same order/shape as params; NULL = not wanted; SPyNet entries
- * are ignored: train_flow=False, basicvsr.py:25-28) are ACCUMULATED into (+=).                */
+ * (need_backward >= 1).  grads[k] (same order/shape as params; NULL = not wanted) are ACCUMULATED
+ * into (+=).  SPyNet entries: all NULL = frozen flow net; otherwise the forward must have run with
+ * need_backward = 2 and all 60 conv tensors get their gradient (flow gradient of the propagation
+ * warps, spynet.py:95-106, then SPyNet's own backward, spynet.py:38-93).                         */
 int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads,
                           int nparams, const float* lrs, const float* dsr, void* workspace,
                           size_t workspace_bytes, void* stream);
@@ -80,10 +84,15 @@ int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, floa
 
 /* ---- SPyNet alone: flow = Spynet(ref, supp)  (RealBasicVSR/modules/spynet.py:69-93) -------
  * ref/supp (N,3,h,w) fp32 planar; params: the 62 spynet tensors in state_dict order.        */
-size_t vsr_spynet_workspace_bytes(int N, int h, int w, int dtype);
+size_t vsr_spynet_workspace_bytes(int N, int h, int w, int dtype, int need_backward);
 int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* params, int nparams,
                        const float* ref, const float* supp, float* flow, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       size_t workspace_bytes, int need_backward, void* stream);
+/* Parameter gradients of the forward that last ran on `workspace` with need_backward = 1, for the
+ * cotangent dflow (N,2,h,w): grads[k] += d<flow, dflow>/d params[k] for the 60 conv tensors (NULL =
+ * not wanted; a bias needs its weight's entry).  ref / supp are not differentiated.             */
+int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int nparams,
+                        const float* dflow, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- RealBasicVSR pre-clean stack, forward: lq = IterativeRefinement(lr) ----------------------
  * (vsr/models/RealBasicVSR/realbasicvsr.py:17-30): `steps` times x <- x + conv(ResidualBlock(x)) on
@@ -102,6 +111,10 @@ int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out
 /* its backward w.r.t. `in`: dacc (fp32 pixel-major, caller-zeroed) += scatter(dout)           */
 int vsr_flow_warp_bwd(int dtype, const void* dout_pm, const float* flow, float* dacc_pm_f32, int N,
                       int H, int W, int C, void* stream);
+
+/* its backward w.r.t. the flow (grid_sampler_2d_backward's grid gradient): dflow (N,2,H,W) fp32   */
+int vsr_flow_warp_bwd_flow(int dtype, const void* in_pm, const void* dout_pm, const float* flow,
+                           float* dflow, int N, int H, int W, int C, void* stream);
 
 /* layout converters between the reference's planar fp32 and pixel-major `dtype`              */
 int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int C,

@@ -145,5 +145,49 @@ def main():
     save("realbasicvsr_m64", seed_lr=14, sr=sr, lq=lq)
 
 
+def proj_vector(key, shape):
+    """Seeded random direction for a parameter (a function of its state_dict key): gradients too large to store
+    are pinned by <grad, proj_vector>, their sum and their L2 norm.  tests/helpers.py holds the same function."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(("proj:" + key).encode()) & 0x7fffffff)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def trainflow():
+    """BasicVSR with train_flow=True (conf/experiment/basic.yaml:7): the gradients of all 60 SPyNet tensors, through
+    the propagation warps' flow gradient, the pyramid's border warps and x2 upsampling (spynet.py:38-106)."""
+    torch.set_num_threads(8)
+    basicvsr, spynet, realbasicvsr, conv, upsampling = import_reference()
+    mid, blocks, shape = 64, 3, (2, 3, 3, 24, 40)               # same clip / weights / cotangent as basicvsr_m64_rb3
+    m = load_keyed(basicvsr.BasicVSR(mid, blocks, 4, False, True)).double()
+    lrs = rand(10, *shape).double()
+    n, t, _, h, w = shape
+    sr = m(lrs)
+    cot = rand(13, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1).double()
+    torch.mean(sr * cot).backward()
+    named = dict(m.named_parameters())
+    spy = [k for k in named if k.startswith("spynet.")]
+    assert len(spy) == 60 and all(named[k].grad is not None for k in spy)
+    stats = torch.stack([torch.stack([named[k].grad.sum(), named[k].grad.norm(),
+                                      (named[k].grad * proj_vector(k, named[k].shape)).sum()]) for k in spy])
+    full = ["spynet.basic_module.5.basic_module.0.conv.0.weight", "spynet.basic_module.5.basic_module.4.conv.0.weight",
+            "spynet.basic_module.5.basic_module.4.conv.0.bias", "spynet.basic_module.3.basic_module.1.conv.0.bias",
+            "spynet.basic_module.2.basic_module.3.conv.0.weight", "spynet.basic_module.0.basic_module.4.conv.0.weight",
+            "spynet.basic_module.0.basic_module.0.conv.0.bias"]
+    grads = {"grad__" + k.replace(".", "__"): named[k].grad for k in full}
+    trunk = ["backward_resblocks.conv.0.weight", "conv_last.2.weight"]     # unchanged by train_flow: cross-check
+    grads.update({"grad__" + k.replace(".", "__"): named[k].grad for k in trunk})
+    out = {k: v.detach().numpy().astype(np.float64) for k, v in grads.items()}
+    out["spy_stats"] = stats.detach().numpy().astype(np.float64)
+    out["spy_keys"] = np.array(spy)
+    out["seed_lr"] = np.asarray(10); out["seed_cot"] = np.asarray(13)
+    np.savez_compressed(os.path.join(HERE, "basicvsr_m64_rb3_trainflow.npz"), **out)
+    print("basicvsr_m64_rb3_trainflow", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "trainflow":
+        trainflow()
+    else:
+        main()
+        trainflow()

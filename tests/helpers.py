@@ -28,3 +28,11 @@ def rel_l2(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def proj_vector(key, shape):
+    """Seeded random direction for a parameter (same function as tests/golden/make_golden.py): gradients too
+    large to store are pinned by <grad, proj_vector>, their sum and their L2 norm."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(("proj:" + key).encode()) & 0x7fffffff)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)

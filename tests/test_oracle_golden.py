@@ -84,6 +84,36 @@ def test_basicvsr_end_to_end_fwd_bwd(tag, mid, blocks, shape):
     assert not any("spynet" in k for k in grads)       # frozen flow net: basicvsr.py:25-28
 
 
+def test_basicvsr_train_flow_spynet_grads():
+    """train_flow=True (conf/experiment/basic.yaml:7): all 60 SPyNet gradients of the oracle against the reference's,
+    float64 on both sides; 7 tensors in full, every tensor through (sum, L2 norm, seeded projection)."""
+    import os
+    import numpy as np
+    from helpers import GOLDEN, proj_vector
+    with np.load(os.path.join(GOLDEN, "basicvsr_m64_rb3_trainflow.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    shape = (2, 3, 3, 24, 40)
+    n, t, _, h, w = shape
+    sd = {k: v.double() for k, v in O.keyed_state_dict(O.basicvsr_param_shapes(64, 3, 4)).items()}
+    lrs = rand(int(g["seed_lr"]), *shape).double()
+    cot = rand(int(g["seed_cot"]), n, t, 3, 4 * h, 4 * w, lo=-1, hi=1).double()
+    _, _, grads = O.fwd_bwd(sd, lrs, torch.zeros(n, t, 3, 4 * h, 4 * w, dtype=torch.float64), train_flow=True, cot=cot)
+    keys = [str(k) for k in g["spy_keys"]]
+    assert len(keys) == 60
+    for i, k in enumerate(keys):
+        gk = grads[k]
+        st = torch.stack([gk.sum(), gk.norm(), (gk * proj_vector(k, gk.shape)).sum()])
+        ref = torch.from_numpy(g["spy_stats"][i])
+        assert float((st - ref).abs().max()) < 1e-6 * float(ref[1]) + 1e-18, k
+    full = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            name = k[len("grad__"):].replace("__", ".")
+            assert rel_err(grads[name], torch.from_numpy(v)) < 1e-6, name
+            full += 1
+    assert full == 9
+
+
 def test_realbasicvsr_forward():
     g = golden("realbasicvsr_m16")
     shapes = {"basicvsr." + k: s for k, s in O.basicvsr_param_shapes(16, 2, 4).items()}

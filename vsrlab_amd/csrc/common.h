@@ -82,6 +82,8 @@ struct WgradArgs {
     int x_step, x_oy, x_ox, Hx, Wx;   // x view -> underlying image
     int dy_step, dy_oy, dy_ox, Hy, Wy; // dy view -> underlying image
     float* slab;                 // [gridDim.x][slab_stride] fp32 partials
+    int tap_begin;               // first tap of this launch (7x7 kernels go one kernel row per launch)
+    int x_ctotal, x_coff;        // generic kernel: channels per pixel of the X tensor (0 = CX) and first 8-channel chunk used
     int slab_stride;
     int ntiles_x, ntiles_y;
 };

@@ -292,6 +292,178 @@ __global__ void flow_out_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
+// ---- train_flow: gradients w.r.t. the optical flow (spynet.py:95-106 backward, basicvsr.py:25-28) --------------
+// d flow of flow_warp(in, flow) with zeros padding (the propagation warps): grid_sampler_2d_backward's grid
+// gradient; with align_corners=True and the reference's normalisation d(sample x)/d(flow x) = 1 (0 if W == 1).
+//   dflow[n][0][y][x] = sum_c dout[c] * ( wy0*(in[y0][x1]-in[y0][x0]) + wy1*(in[y1][x1]-in[y1][x0]) )   (OOB taps = 0)
+// One thread per pixel, looping over the 8-channel chunks.
+template <typename T>
+__global__ void warp_bwd_flow_kernel(const T* __restrict__ in, const T* __restrict__ dout, const float* __restrict__ flow,
+                                     float* __restrict__ dflow, int N, int H, int W, int C, long long flow_nstride) {
+    typedef typename EW<T>::chunk_t chunk_t;
+    const int CP = C / 8;
+    const long long total = (long long)N * H * W;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
+        const float px = warp_coord((float)x, fp[0], W);
+        const float py = warp_coord((float)y, fp[(long long)H * W], H);
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const T* img = in + (long long)n * pm_image_elems(H, W, C);
+        const T* dimg = dout + (long long)n * pm_image_elems(H, W, C);
+        float gx = 0.f, gy = 0.f;
+        for (int c = 0; c < CP; ++c) {
+            float g[8], v[4][8];
+            unpack8(*reinterpret_cast<const chunk_t*>(dimg + pm_off(y, x, c, W, C)), g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+                if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+                    unpack8(*reinterpret_cast<const chunk_t*>(img + pm_off(yi, xi, c, W, C)), v[t]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[t][j] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gx += g[j] * (wy0 * (v[1][j] - v[0][j]) + wy1 * (v[3][j] - v[2][j]));
+                gy += g[j] * (wx0 * (v[2][j] - v[0][j]) + wx1 * (v[3][j] - v[1][j]));
+            }
+        }
+        float* dp = dflow + (long long)n * flow_nstride + (long long)y * W + x;
+        dp[0] = W > 1 ? gx : 0.f;
+        dp[(long long)H * W] = H > 1 ? gy : 0.f;
+    }
+}
+
+// d(residue) of a SPyNet level as the 16-channel pixel-major dY of its last conv: the layer ends in a ReLU
+// (spynet.py:16-18), flow = flow_up + residue (spynet.py:65):  out[p][y][x][c] = dflow[p][c][y][x] * (res > 0), c < 2
+template <typename T>
+__global__ void spynet_dres_kernel(const float* __restrict__ dflow, const float* __restrict__ res, T* __restrict__ out,
+                                   int P, int h, int w) {
+    const long long total = (long long)P * h * w;
+    const long long hw = (long long)h * w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const long long p = idx / hw;
+        const long long o = (p * 2) * hw + (long long)y * w + x;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[0] = res[o] > 0.f ? dflow[o] : 0.f;
+        v[1] = res[o + hw] > 0.f ? dflow[o + hw] : 0.f;
+        typename EW<T>::chunk_t lo, hi;
+        pack8(v, lo);
+        pack8(z, hi);
+        T* ob = out + p * pm_image_elems(h, w, 16);
+        *reinterpret_cast<typename EW<T>::chunk_t*>(ob + pm_off(y, x, 0, w, 16)) = lo;
+        *reinterpret_cast<typename EW<T>::chunk_t*>(ob + pm_off(y, x, 1, w, 16)) = hi;
+    }
+}
+
+// Backward of spynet_prepare_kernel w.r.t. the previous level's flow.  Per fine pixel:
+//   g = dflow_l (flow = flow_up + residue)  +  dx16[6..7] (flow_up is a network input)
+//     + d/d(flow_up) of the border-mode warp of the supporting frame, contracted with dx16[3..5]
+//   dflow_prev += 2 * bilinear_x2^T(g)          (atomics; dflow_prev is zeroed by the caller)
+template <typename T>
+__global__ void spynet_prepare_bwd_kernel(const T* __restrict__ dx16, const float* __restrict__ dflow_l,
+                                          const float* __restrict__ frames, const float* __restrict__ flow_up,
+                                          float* __restrict__ dflow_prev, int n, int t, int P, int pair_mode, int h, int w) {
+    const long long total = (long long)P * h * w;
+    const int hp = h / 2, wp = w / 2;
+    const float sy = hp > 1 ? (float)(hp - 1) / (float)(h - 1) : 0.f;
+    const float sx = wp > 1 ? (float)(wp - 1) / (float)(w - 1) : 0.f;
+    const long long hw = (long long)h * w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const int p = (int)(idx / hw);
+        int fsup;
+        if (pair_mode) {
+            fsup = P + p;
+        } else {
+            const int half = P / 2;
+            const int q = p < half ? p : p - half;
+            const int b = q / (t - 1), i = q % (t - 1);
+            fsup = p < half ? b * t + i + 1 : b * t + i;
+        }
+        float d[8];
+        unpack8(*reinterpret_cast<const typename EW<T>::chunk_t*>(dx16 + (long long)p * pm_image_elems(h, w, 16) + pm_off(y, x, 0, w, 16)), d);
+        const float fu0 = flow_up[((long long)p * 2 + 0) * hw + (long long)y * w + x];
+        const float fu1 = flow_up[((long long)p * 2 + 1) * hw + (long long)y * w + x];
+        float px = warp_coord((float)x, fu0, w), py = warp_coord((float)y, fu1, h);
+        // border padding: clip_coordinates_set_grad (the gradient is 0 where the coordinate was clipped)
+        const float mx = (px <= 0.f || px >= (float)(w - 1)) ? 0.f : 1.f;
+        const float my = (py <= 0.f || py >= (float)(h - 1)) ? 0.f : 1.f;
+        px = fminf(fmaxf(px, 0.f), (float)(w - 1));
+        py = fminf(fmaxf(py, 0.f), (float)(h - 1));
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const bool x1ok = x0 + 1 < w, y1ok = y0 + 1 < h;
+        const int x1 = x1ok ? x0 + 1 : x0, y1 = y1ok ? y0 + 1 : y0;
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        float gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* sp = frames + ((long long)fsup * 3 + c) * hw;
+            const float v00 = sp[y0 * w + x0];
+            const float v01 = x1ok ? sp[y0 * w + x1] : 0.f;
+            const float v10 = y1ok ? sp[y1 * w + x0] : 0.f;
+            const float v11 = (x1ok && y1ok) ? sp[y1 * w + x1] : 0.f;
+            gx += d[3 + c] * (wy0 * (v01 - v00) + wy1 * (v11 - v10));
+            gy += d[3 + c] * (wx0 * (v10 - v00) + wx1 * (v11 - v01));
+        }
+        float g[2];
+        g[0] = d[6] + (w > 1 ? gx * mx : 0.f);
+        g[1] = d[7] + (h > 1 ? gy * my : 0.f);
+        if (dflow_l) {
+            g[0] += dflow_l[((long long)p * 2 + 0) * hw + (long long)y * w + x];
+            g[1] += dflow_l[((long long)p * 2 + 1) * hw + (long long)y * w + x];
+        }
+        int yy0, yy1, xx0, xx1; float ly, lx;
+        src_index(y, sy, hp, true, yy0, yy1, ly);
+        src_index(x, sx, wp, true, xx0, xx1, lx);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float* dp = dflow_prev + ((long long)p * 2 + c) * hp * wp;
+            const float v = 2.0f * g[c];
+            atomicAdd(dp + yy0 * wp + xx0, v * (1.f - ly) * (1.f - lx));
+            atomicAdd(dp + yy0 * wp + xx1, v * (1.f - ly) * lx);
+            atomicAdd(dp + yy1 * wp + xx0, v * ly * (1.f - lx));
+            atomicAdd(dp + yy1 * wp + xx1, v * ly * lx);
+        }
+    }
+}
+
+// Backward of flow_out_kernel: din (P,2,hu,wu) += resize^T(dout (P,2,h,w)) * scale   (din zeroed by the caller)
+__global__ void flow_out_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int P, int hu, int wu, int h, int w) {
+    const long long total = (long long)P * 2 * h * w;
+    const float sy = (float)hu / (float)h, sx = (float)wu / (float)w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const int c = (int)((idx / ((long long)w * h)) % 2);
+        const long long p = idx / ((long long)w * h * 2);
+        int y0, y1, x0, x1; float ly, lx;
+        src_index(y, sy, hu, false, y0, y1, ly);
+        src_index(x, sx, wu, false, x0, x1, lx);
+        float* ip = din + (p * 2 + c) * (long long)hu * wu;
+        const float v = dout[idx] * (c == 0 ? (float)w / (float)wu : (float)h / (float)hu);
+        atomicAdd(ip + y0 * wu + x0, v * (1.f - ly) * (1.f - lx));
+        atomicAdd(ip + y0 * wu + x1, v * (1.f - ly) * lx);
+        atomicAdd(ip + y1 * wu + x0, v * ly * (1.f - lx));
+        atomicAdd(ip + y1 * wu + x1, v * ly * lx);
+    }
+}
+
+__global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
 // OIHW fp32 -> packed T [tap][R][Cc] consumed by conv_mfma (A operand rows = R, K = Cc).
 //   mode 0 (forward):  dst[tap][r][c] = w[r*o_mul + o_add][i_off + c][tap]
 //   mode 1 (data grad): dst[tap][r][c] = w[c*o_mul + o_add][i_off + r][KK-1-tap]   (flipped taps, roles swapped)
@@ -395,6 +567,39 @@ int vsr_launch_spynet_prepare(int dtype, const float* frames, const float* flow_
 
 int vsr_launch_flow_out(const float* in, float* out, int P, int hu, int wu, int h, int w, hipStream_t st) {
     hipLaunchKernelGGL(flow_out_kernel, dim3(grid_for((long long)P * 2 * h * w)), dim3(256), 0, st, in, out, P, hu, wu, h, w);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_warp_bwd_flow(int dtype, const void* in, const void* dout, const float* flow, float* dflow, int N, int H, int W,
+                             int C, long long flow_nstride, hipStream_t st) {
+    if (C % 8) return VSR_ERR_BADARG;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_flow_kernel<T>, dim3(grid_for((long long)N * H * W)), dim3(256), 0, st, (const T*)in, (const T*)dout, flow, dflow, N, H, W, C, flow_nstride));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_spynet_dres(int dtype, const float* dflow, const float* res, void* out, int P, int h, int w, hipStream_t st) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(spynet_dres_kernel<T>, dim3(grid_for((long long)P * h * w)), dim3(256), 0, st, dflow, res, (T*)out, P, h, w));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_spynet_prepare_bwd(int dtype, const void* dx16, const float* dflow_l, const float* frames, const float* flow_up,
+                                  float* dflow_prev, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(spynet_prepare_bwd_kernel<T>, dim3(grid_for((long long)P * h * w)), dim3(256), 0, st, (const T*)dx16, dflow_l, frames, flow_up, dflow_prev, n, t, P, pair_mode, h, w));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(flow_out_bwd_kernel, dim3(grid_for((long long)P * 2 * h * w)), dim3(256), 0, st, dout, din, P, hu, wu, h, w);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_add_f32(const float* a, const float* b, float* out, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, out, n);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

@@ -28,6 +28,8 @@ constexpr int NSPY = 5;         // convs per SPyNet level
 const int SPY_CI[NSPY] = {8, 32, 64, 32, 16}, SPY_CO[NSPY] = {32, 64, 32, 16, 2};
 const int SPY_CIP[NSPY] = {16, 32, 64, 32, 16}, SPY_COP[NSPY] = {32, 64, 32, 32, 32};   // padded (template) sizes
 const int SPY_CD[NSPY] = {32, 64, 32, 16, 0};     // channels per pixel of each layer's pixel-major output
+// backward (train_flow): pixel-major channels of each layer's dY, and the dgrad launch's template rows (COUT)
+const int SPY_DK[NSPY] = {32, 64, 32, 16, 16}, SPY_DROWS[NSPY] = {32, 32, 64, 32, 32};
 
 struct SpyPlan {
     int P, F, h, w, hu, wu;
@@ -35,6 +37,28 @@ struct SpyPlan {
     size_t x16, b32a, b64, b32b, b16;   // pixel-major T at the finest level size
     size_t flow_a, flow_b, flow_up;     // planar fp32 [P][2][hu][wu]
     size_t wpack[6][NSPY], bias[6][NSPY];
+    // train_flow (need_backward = 2): per-level saved activations, dgrad weights and backward scratch
+    bool save = false;
+    size_t sx[6][NSPY];                 // inputs of the 5 convs of each level: x16, b32a, b64, b32b, b16
+    size_t sfup[6], sres[6];            // planar fp32 flow_up and residue (= ReLU(conv5)) per level
+    size_t wpackd[6][NSPY];
+    size_t gA, gB, dres, dfa, dfb;
+    void plan_save(Bump& b, int dtype) {
+        save = true;
+        const size_t es = esize(dtype);
+        for (int l = 0; l < 6; ++l) {
+            const int hl = hu >> (5 - l), wl = wu >> (5 - l);
+            for (int j = 0; j < NSPY; ++j) sx[l][j] = b.take((size_t)P * pm_image_elems(hl, wl, SPY_CIP[j]) * es);
+            sfup[l] = b.take((size_t)P * 2 * hl * wl * 4);
+            sres[l] = b.take((size_t)P * 2 * hl * wl * 4);
+            for (int j = 0; j < NSPY; ++j) wpackd[l][j] = b.take((size_t)49 * 64 * 64 * es);
+        }
+        gA = b.take((size_t)P * pm_image_elems(hu, wu, 64) * es);
+        gB = b.take((size_t)P * pm_image_elems(hu, wu, 64) * es);
+        dres = b.take((size_t)P * pm_image_elems(hu, wu, 16) * es);
+        dfa = b.take((size_t)P * 2 * hu * wu * 4);
+        dfb = b.take((size_t)P * 2 * hu * wu * 4);
+    }
     void plan(Bump& b, int P_, int F_, int h_, int w_, int dtype) {
         P = P_; F = F_; h = h_; w = w_;
         wu = (w % 32) == 0 ? w : 32 * (w / 32 + 1);      // spynet.py:72-73
@@ -59,7 +83,7 @@ struct SpyPlan {
 
 struct Plan {
     VsrBasicVSRDesc d;
-    bool bwd;
+    bool bwd, flowgrad;          // flowgrad: train_flow (basicvsr.py:25-28), SPyNet is differentiated too
     int rb, n, t, h, w, dtype;
     size_t es;
     size_t px1;                 // elements of one blocked (n,h,w,64) tensor
@@ -83,6 +107,7 @@ struct Plan {
     std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
     size_t S[2], dWp[2], slab[2];               // per direction / stream
     size_t G_C0, G_U1, G_U0, G_P;
+    size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow)
     size_t total;
 
     size_t xoff(int dir, int i, int b) const { return X[dir][(size_t)i * (rb + 1) + b]; }
@@ -90,8 +115,8 @@ struct Plan {
     size_t g1off(int dir, int i, int b) const { return G1[dir][(size_t)i * rb + b]; }
     size_t dxoff(int dir, int i, int b) const { return DX[dir][(size_t)i * (rb + 1) + b]; }
 
-    int build(const VsrBasicVSRDesc& desc, bool need_backward) {
-        d = desc; bwd = need_backward;
+    int build(const VsrBasicVSRDesc& desc, int mode) {     // 0 inference, 1 training (frozen flow), 2 training incl. SPyNet
+        d = desc; bwd = mode >= 1; flowgrad = mode >= 2;
         rb = d.res_blocks; n = d.n; t = d.t; h = d.h; w = d.w; dtype = d.dtype;
         if (d.mid_channels != C || d.upscale != 4 || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
         if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
@@ -150,6 +175,12 @@ struct Plan {
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+        }
+        // appended last, so that every other offset is the same in modes 1 and 2
+        dflows = 0;
+        if (flowgrad && t > 1) {
+            dflows = b.take((size_t)2 * n * (t - 1) * 2 * h * w * 4);
+            spy.plan_save(b, dtype);
         }
         total = b.off;
         return VSR_OK;
@@ -240,6 +271,8 @@ int spynet_pack(const Ctx& c, const SpyPlan& sp, const float* const* params, int
             const float* b = params[base_idx + (l * NSPY + j) * 2 + 1];
             CK(c.pack(w, sp.wpack[l][j], 49, SPY_COP[j], SPY_CIP[j], SPY_CO[j], SPY_CI[j], SPY_CI[j], 0, 1, 0, 0));
             CK(c.pack_bias(b, sp.bias[l][j], SPY_CO[j]));
+            // data-gradient weights: rows = the conv's input channels (template COUT of the dgrad launch), K = its outputs
+            if (sp.save) CK(c.pack(w, sp.wpackd[l][j], 49, SPY_DROWS[j], SPY_DK[j], SPY_CI[j], SPY_CO[j], SPY_CI[j], 0, 1, 0, 1));
         }
     return VSR_OK;
 }
@@ -253,9 +286,11 @@ int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float
     size_t fprev = sp.flow_a, fcur = sp.flow_b;
     for (int l = 0; l < 6; ++l) {
         const int hl = hu >> (5 - l), wl = wu >> (5 - l);
-        CK(vsr_launch_spynet_prepare(c.dtype, c.fat(sp.pyr[l]), l == 0 ? nullptr : c.fat(fprev), (float*)c.at(sp.flow_up), c.at(sp.x16),
+        const size_t fup = sp.save ? sp.sfup[l] : sp.flow_up;
+        const size_t bufs[NSPY + 1] = {sp.save ? sp.sx[l][0] : sp.x16, sp.save ? sp.sx[l][1] : sp.b32a, sp.save ? sp.sx[l][2] : sp.b64,
+                                       sp.save ? sp.sx[l][3] : sp.b32b, sp.save ? sp.sx[l][4] : sp.b16, 0};
+        CK(vsr_launch_spynet_prepare(c.dtype, c.fat(sp.pyr[l]), l == 0 ? nullptr : c.fat(fprev), (float*)c.at(fup), c.at(bufs[0]),
                                      n, t, P, pair_mode, hl, wl, l == 0, c.st));
-        const size_t bufs[NSPY + 1] = {sp.x16, sp.b32a, sp.b64, sp.b32b, sp.b16, 0};
         for (int j = 0; j < NSPY; ++j) {
             ConvArgs a = c.base(P, hl, wl);
             a.src[0] = c.at(bufs[j]); a.src_nstride[0] = pm_image_elems(hl, wl, SPY_CIP[j]);
@@ -264,9 +299,13 @@ int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float
             if (j < NSPY - 1) {
                 a.dst[0] = c.at(bufs[j + 1]); a.CD = SPY_CD[j]; a.dst_nstride = pm_image_elems(hl, wl, SPY_CD[j]);
                 CK(vsr_launch_conv(c.dtype, 7, 1, SPY_CIP[j], SPY_CIP[j], 0, SPY_COP[j], EPI_NHWC, a, c.st));
-            } else {
-                a.dst[0] = c.at(fcur); a.dst_nstride = (long long)2 * hl * wl; a.pres = c.fat(sp.flow_up);   // flow = flow_up + residue (spynet.py:65)
+            } else if (!sp.save) {
+                a.dst[0] = c.at(fcur); a.dst_nstride = (long long)2 * hl * wl; a.pres = c.fat(fup);   // flow = flow_up + residue (spynet.py:65)
                 CK(vsr_launch_conv(c.dtype, 7, 1, 16, 16, 0, 32, EPI_PLANAR, a, c.st));
+            } else {                                           // keep the residue: its sign is the last ReLU's mask
+                a.dst[0] = c.at(sp.sres[l]); a.dst_nstride = (long long)2 * hl * wl;
+                CK(vsr_launch_conv(c.dtype, 7, 1, 16, 16, 0, 32, EPI_PLANAR, a, c.st));
+                CK(vsr_launch_add_f32(c.fat(fup), c.fat(sp.sres[l]), (float*)c.at(fcur), (long long)P * 2 * hl * wl, c.st));
             }
         }
         size_t tmp = fprev; fprev = fcur; fcur = tmp;
@@ -448,7 +487,12 @@ struct WG {   // one weight-gradient launch + reduction
         vsr_wgrad_slab_dims(ks, cx, cout, &cp, &xpd, &stride);
         a.slab = (float*)c.at(c.p.slab[c.lane]); a.slab_stride = stride;
         const int tiles = a.N * cdiv(a.H, 8) * cdiv(a.W, 32);
-        const int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
+        int cp3, xp3, stride3;
+        vsr_wgrad_slab_dims(3, 64, 64, &cp3, &xp3, &stride3);          // the slab buffer holds VSR_WGRAD_NWG of these
+        const long long cap = (long long)VSR_WGRAD_NWG * stride3 / stride;
+        int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
+        if (nwg > cap) nwg = (int)cap;
+        if (nwg > 1) nwg &= ~1;
         CK(vsr_launch_wgrad(c.dtype, ks, cx, xp, cout, dyp, a, nwg, c.st));
         if (!gw) return VSR_ERR_BADARG;
         return vsr_launch_wgrad_reduce(a.slab, nwg, ks, cx, cout, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, 1, c.st);
@@ -461,6 +505,58 @@ WgradArgs wg_base(int N, int H, int W) {
     a.x_step = 1; a.Hx = H; a.Wx = W; a.x_nstride = pm_image_elems(H, W, C);
     a.dy_step = 1; a.Hy = H; a.Wy = W; a.dy_nstride = pm_image_elems(H, W, C);
     return a;
+}
+
+// Backward of spynet_run for train_flow (spynet.py:38-93): dflows_out = d loss / d flows (P,2,h,w) ->
+// weight / bias gradients of the 6 x 5 convs (g[base_idx ...], OIHW fp32).  The frames are not differentiated.
+int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, int n, int t, int pair_mode, float* const* g,
+                    int base_idx) {
+    const WG wg{c};
+    const int P = sp.P, hu = sp.hu, wu = sp.wu;
+    size_t dcur = sp.dfa, dprev = sp.dfb;
+    HIP_CHECK_RET(hipMemsetAsync(c.at(dcur), 0, (size_t)P * 2 * hu * wu * 4, c.st));
+    CK(vsr_launch_flow_out_bwd(dflows_out, (float*)c.at(dcur), P, hu, wu, sp.h, sp.w, c.st));
+    for (int l = 5; l >= 0; --l) {
+        const int hl = hu >> (5 - l), wl = wu >> (5 - l);
+        // flow_l = flow_up + ReLU(conv5): dY of the last conv, as a 16-channel pixel-major tensor
+        CK(vsr_launch_spynet_dres(c.dtype, c.fat(dcur), c.fat(sp.sres[l]), c.at(sp.dres), P, hl, wl, c.st));
+        size_t dy = sp.dres;
+        for (int j = NSPY - 1; j >= 0; --j) {
+            const int CI = SPY_CIP[j], CO = SPY_DK[j];
+            float* gw = g[base_idx + (l * NSPY + j) * 2];
+            float* gb = g[base_idx + (l * NSPY + j) * 2 + 1];
+            if (gw || gb) {
+                // fp32, 64 input channels: two 32-channel halves (the 14x38-pixel fp32 tile of 64 channels exceeds LDS)
+                const int nhalf = (c.dtype == VSR_F32 && CI == 64) ? 2 : 1;
+                for (int hf = 0; hf < nhalf; ++hf) {
+                    WgradArgs a = wg_base(P, hl, wl);
+                    a.x[0] = c.at(sp.sx[l][j]); a.x_nstride = pm_image_elems(hl, wl, CI);
+                    a.dy[0] = c.at(dy); a.dy_nstride = pm_image_elems(hl, wl, CO);
+                    const int cx = CI / nhalf;
+                    if (nhalf == 2) { a.x_ctotal = CI; a.x_coff = hf * (cx / 8); }
+                    const int cin_real = nhalf == 2 ? cx : SPY_CI[j];
+                    CK(wg.run(7, cx, false, CO, false, a, SPY_CO[j], cin_real, gw, SPY_CI[j], hf * cx, 1, 0, hf == 0 ? gb : nullptr));
+                }
+            }
+            if (j == 0 && l == 0) break;                   // level 0's input does not depend on anything differentiated
+            // dX_j = dgrad(conv_j)(dY_j) (* ReLU'(X_j) for j > 0: X_j is the previous conv's ReLU output)
+            const size_t dx = (dy == sp.gA) ? sp.gB : sp.gA;
+            ConvArgs a = c.base(P, hl, wl);
+            a.src[0] = c.at(dy); a.src_nstride[0] = pm_image_elems(hl, wl, CO);
+            a.wpack = c.at(sp.wpackd[l][j]); a.dst[0] = c.at(dx);
+            a.CD = CI; a.cout_real = j == 0 ? 8 : CI; a.dst_nstride = pm_image_elems(hl, wl, CI);
+            if (j > 0) { a.aux[0] = c.at(sp.sx[l][j]); a.mask_mode = MASK_RELU; }
+            CK(vsr_launch_conv(c.dtype, 7, 1, CO, CO, 0, SPY_DROWS[j], EPI_NHWC, a, c.st));
+            dy = dx;
+        }
+        if (l == 0) break;
+        // x16 = [ref | warp(supp, flow_up) | flow_up], flow_up = 2 * up(flow_{l-1}): everything that reaches flow_{l-1}
+        HIP_CHECK_RET(hipMemsetAsync(c.at(dprev), 0, (size_t)P * 2 * (hl / 2) * (wl / 2) * 4, c.st));
+        CK(vsr_launch_spynet_prepare_bwd(c.dtype, c.at(dy), c.fat(dcur), c.fat(sp.pyr[l]), c.fat(sp.sfup[l]), (float*)c.at(dprev),
+                                         n, t, P, pair_mode, hl, wl, c.st));
+        const size_t tmp = dcur; dcur = dprev; dprev = tmp;
+    }
+    return VSR_OK;
 }
 
 int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g) {
@@ -583,6 +679,11 @@ int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float
         if (!last) {   // feat(i) = trunk(warp(feat(prev), flow)): scatter the gradient of the warped state back
             HIP_CHECK_RET(hipMemsetAsync(c.at(p.S[dir]), 0, p.s_elems * 4, c.st));
             CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp[dir]), flow_ptr(c, p, dir, dir == 1 ? i - 1 : i), (float*)c.at(p.S[dir]), n, h, w, C, fstride, c.st));
+            if (p.flowgrad) {   // the same warp's gradient w.r.t. its flow (each flow is used by exactly one warp)
+                const int prev = dir == 1 ? i - 1 : i + 1, fi = dir == 1 ? i - 1 : i;
+                float* df = (float*)c.at(p.dflows) + ((size_t)dir * p.n * (p.t - 1) + fi) * 2 * p.h * p.w;
+                CK(vsr_launch_warp_bwd_flow(c.dtype, c.at(p.feat[dir][prev]), c.at(p.dWp[dir]), flow_ptr(c, p, dir, fi), df, n, h, w, C, fstride, c.st));
+            }
         }
     }
     return trunk_wgrads(c, p, dir, lrs, g);
@@ -598,7 +699,10 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     const Ctx c1{p, ws, f.side(), p.dtype, 1};
     CK(backward_chain(c, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
-    return f.end();
+    CK(f.end());
+    if (p.flowgrad && p.t > 1)
+        CK(spynet_backward(c, p.spy, c.fat(p.dflows), p.n, p.t, 0, g, PIdx{p.rb}.spy_base()));
+    return VSR_OK;
 }
 
 }  // namespace
@@ -627,7 +731,7 @@ int vsr_basicvsr_num_params(const VsrBasicVSRDesc* d) {
 size_t vsr_basicvsr_workspace_bytes(const VsrBasicVSRDesc* d, int need_backward) {
     if (!d) return 0;
     Plan p;
-    if (p.build(*d, need_backward != 0) != VSR_OK) return 0;
+    if (p.build(*d, need_backward) != VSR_OK) return 0;
     return p.total;
 }
 
@@ -635,7 +739,7 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
                          void* workspace, size_t workspace_bytes, int need_backward, void* stream) {
     if (!d || !params || !lrs || !sr || !workspace) return VSR_ERR_BADARG;
     Plan p;
-    CK(p.build(*d, need_backward != 0));
+    CK(p.build(*d, need_backward));
     if (nparams != PIdx{p.rb}.count()) return VSR_ERR_BADARG;
     for (int k = 0; k < nparams; ++k) if (!params[k]) return VSR_ERR_BADARG;
     if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
@@ -645,9 +749,13 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
 int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads, int nparams,
                           const float* lrs, const float* dsr, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !grads || !lrs || !dsr || !workspace) return VSR_ERR_BADARG;
+    if (d->res_blocks < 1) return VSR_ERR_UNSUPPORTED;
+    const PIdx ix{d->res_blocks};
+    if (nparams != ix.count()) return VSR_ERR_BADARG;
+    bool flow = false;                                     // any SPyNet gradient wanted => the forward ran with need_backward = 2
+    for (int k = ix.spy_base(); k < ix.spy_mean(); ++k) flow = flow || grads[k];
     Plan p;
-    CK(p.build(*d, true));
-    if (nparams != PIdx{p.rb}.count()) return VSR_ERR_BADARG;
+    CK(p.build(*d, flow ? 2 : 1));
     if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
     return backward_impl(p, params, grads, lrs, dsr, (char*)workspace, (hipStream_t)stream);
 }
@@ -655,7 +763,7 @@ int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, 
 int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, float* flow_forward, float* flow_backward, void* stream) {
     if (!d || !workspace) return VSR_ERR_BADARG;
     Plan p;
-    CK(p.build(*d, false));     // weight/flow offsets do not depend on need_backward
+    CK(p.build(*d, 0));         // weight/flow offsets do not depend on need_backward
     if (p.t < 2) return VSR_OK;
     const size_t half = (size_t)p.n * (p.t - 1) * 2 * p.h * p.w * 4;
     const char* f = (const char*)workspace + p.flows;
@@ -665,25 +773,32 @@ int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, floa
 }
 
 // ---- SPyNet alone ---------------------------------------------------------------------------------
-struct SpyAlone { SpyPlan sp; size_t frames; size_t total; };
-static SpyAlone spy_alone_plan(int N, int h, int w, int dtype) {
+struct SpyAlone { SpyPlan sp; size_t frames, slab; size_t total; };
+static SpyAlone spy_alone_plan(int N, int h, int w, int dtype, bool save) {
     SpyAlone s; Bump b;
     s.frames = b.take((size_t)2 * N * 3 * h * w * 4);
     s.sp.plan(b, N, 2 * N, h, w, dtype);
+    s.slab = 0;
+    if (save) {                                  // appended: the forward-only offsets do not move
+        s.sp.plan_save(b, dtype);
+        int cp, xp, stride;
+        vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
+        s.slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+    }
     s.total = b.off;
     return s;
 }
 
-size_t vsr_spynet_workspace_bytes(int N, int h, int w, int dtype) {
+size_t vsr_spynet_workspace_bytes(int N, int h, int w, int dtype, int need_backward) {
     if (N < 1 || h < 1 || w < 1) return 0;
-    return spy_alone_plan(N, h, w, dtype).total;
+    return spy_alone_plan(N, h, w, dtype, need_backward != 0).total;
 }
 
 int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* params, int nparams, const float* ref,
-                       const float* supp, float* flow, void* workspace, size_t workspace_bytes, void* stream) {
+                       const float* supp, float* flow, void* workspace, size_t workspace_bytes, int need_backward, void* stream) {
     if (N < 1 || h < 1 || w < 1 || !params || nparams != 62 || !ref || !supp || !flow || !workspace) return VSR_ERR_BADARG;
     if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
-    const SpyAlone s = spy_alone_plan(N, h, w, dtype);
+    const SpyAlone s = spy_alone_plan(N, h, w, dtype, need_backward != 0);
     if (workspace_bytes < s.total) return VSR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Plan dummy; dummy.es = esize(dtype);
@@ -693,6 +808,18 @@ int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* param
     HIP_CHECK_RET(hipMemcpyAsync((char*)c.at(s.frames) + fb, supp, fb, hipMemcpyDeviceToDevice, st));
     CK(spynet_pack(c, s.sp, params, 0));
     return spynet_run(c, s.sp, c.fat(s.frames), params[60], params[61], N, 2, 1, flow);
+}
+
+int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int nparams, const float* dflow, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (N < 1 || h < 1 || w < 1 || !grads || nparams != 62 || !dflow || !workspace) return VSR_ERR_BADARG;
+    if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+    for (int k = 0; k < 60; k += 2) if (!grads[k] && grads[k + 1]) return VSR_ERR_BADARG;   // a bias gradient comes with its weight's
+    const SpyAlone s = spy_alone_plan(N, h, w, dtype, true);
+    if (workspace_bytes < s.total) return VSR_ERR_WORKSPACE;
+    Plan dummy; dummy.es = esize(dtype); dummy.slab[0] = dummy.slab[1] = s.slab;
+    const Ctx c{dummy, (char*)workspace, (hipStream_t)stream, dtype};
+    return spynet_backward(c, s.sp, dflow, N, 2, 1, grads, 0);
 }
 
 // ---- RealBasicVSR pre-clean stack, forward (realbasicvsr.py:17-30) ------------------------------------
@@ -767,6 +894,11 @@ int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out
 }
 int vsr_flow_warp_bwd(int dtype, const void* dout_pm, const float* flow, float* dacc, int N, int H, int W, int Cc, void* stream) {
     return vsr_launch_warp_bwd(dtype, dout_pm, flow, dacc, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
+}
+int vsr_flow_warp_bwd_flow(int dtype, const void* in_pm, const void* dout_pm, const float* flow, float* dflow, int N, int H, int W,
+                           int Cc, void* stream) {
+    if (!in_pm || !dout_pm || !flow || !dflow || N < 1 || H < 1 || W < 1) return VSR_ERR_BADARG;
+    return vsr_launch_warp_bwd_flow(dtype, in_pm, dout_pm, flow, dflow, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
 }
 int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int Cc, void* stream) {
     return vsr_launch_planar_to_pm(dtype, in, out_pm, N, Cin, H, W, Cc, (hipStream_t)stream);

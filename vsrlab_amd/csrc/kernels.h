@@ -22,6 +22,13 @@ int vsr_launch_avgpool2(const float* in, float* out, long long planes, int h, in
 int vsr_launch_spynet_prepare(int dtype, const float* frames, const float* flow_prev, float* flow_up, void* x16, int n,
                               int t, int P, int pair_mode, int h, int w, int level0, hipStream_t st);
 int vsr_launch_flow_out(const float* in, float* out, int P, int hu, int wu, int h, int w, hipStream_t st);
+int vsr_launch_warp_bwd_flow(int dtype, const void* in, const void* dout, const float* flow, float* dflow, int N, int H, int W,
+                             int C, long long flow_nstride, hipStream_t st);
+int vsr_launch_spynet_dres(int dtype, const float* dflow, const float* res, void* out, int P, int h, int w, hipStream_t st);
+int vsr_launch_spynet_prepare_bwd(int dtype, const void* dx16, const float* dflow_l, const float* frames, const float* flow_up,
+                                  float* dflow_prev, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st);
+int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu, int h, int w, hipStream_t st);
+int vsr_launch_add_f32(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
                             int I_total, int i_off, int o_mul, int o_add, int mode, hipStream_t st);
 int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps,

@@ -73,7 +73,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int NIB = CX >= 32 ? CX / 32 : 1;
     constexpr int NT = NCB * NIB;                 // (cout-block, cin-block) pairs: 1, 2 or 4
     constexpr int TAPSPLIT = 4 / NT;              // waves sharing one pair split the taps
-    constexpr int NTAP = (KK + TAPSPLIT - 1) / TAPSPLIT;
+    // 7x7 (SPyNet): one kernel row of 7 taps per launch (a.tap_begin = 7 ky), or 49 taps would need ~400 accumulator
+    // registers per wave; the slab collects all 49 taps over the 7 launches and is reduced once.
+    constexpr int KT = KS == 7 ? 7 : KK;
+    constexpr int NTAP = (KT + TAPSPLIT - 1) / TAPSPLIT;
     constexpr int COUTP = NCB * 32, CXP = NIB * 32;
     constexpr int XBYTES = NPIXX * CPX * CHB;
     typedef typename WElt<T>::chunk_t chunk_t;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                     const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
                     chunk_t v = wzero<T>();
                     if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c, a.Wx, CX);
+                        const long long o = pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c + a.x_coff, a.Wx, a.x_ctotal ? a.x_ctotal : CX);
                         v = *reinterpret_cast<const chunk_t*>(base + o);
                     }
                     *reinterpret_cast<chunk_t*>(lx + (p * CPX + wswz<CPX>(p, c)) * CHB) = v;
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                         { union { s16x4_t s[2]; bf16x8_t b; } u; u.s[0] = a0; u.s[1] = a1; af = u.b; }
 #pragma unroll
                         for (int i = 0; i < NTAP; ++i) {
-                            const int tap = tap0 + i * TAPSPLIT;
-                            if (tap < KK) {
+                            const int tap = a.tap_begin + tap0 + i * TAPSPLIT;
+                            if (tap0 + i * TAPSPLIT < KT) {
                                 const int ky = tap / KS, kx = tap - ky * KS;
                                 const int px = (row + ky) * TWH + xk + kx + 8 * h + q;
                                 const s16x4_t b0 = tr_read(lx + lds_addr<T, CPX>(px, chx));
@@ -202,8 +205,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                             const float av = *reinterpret_cast<const float*>(ly + lds_addr<T, CPY>(py, chy));
 #pragma unroll
                             for (int i = 0; i < NTAP; ++i) {
-                                const int tap = tap0 + i * TAPSPLIT;
-                                if (tap < KK) {
+                                const int tap = a.tap_begin + tap0 + i * TAPSPLIT;
+                                if (tap0 + i * TAPSPLIT < KT) {
                                     const int ky = tap / KS, kx = tap - ky * KS;
                                     const int px = (row + ky) * TWH + xk + kx + 2 * j + h;
                                     const float bv = *reinterpret_cast<const float*>(lx + lds_addr<T, CPX>(px, chx));
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
 #pragma unroll
     for (int i = 0; i < NTAP; ++i) {
-        const int tap = tap0 + i * TAPSPLIT;
-        if (tap < KK) {
+        const int tap = a.tap_begin + tap0 + i * TAPSPLIT;
+        if (tap0 + i * TAPSPLIT < KT) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -306,8 +309,11 @@ int launch_wgrad_inst(const WgradArgs& a0, int nwg, hipStream_t st) {
     WgradArgs a = a0;
     a.ntiles_x = cdiv(a.W, TW);
     a.ntiles_y = cdiv(a.H, TH);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), LDS, st, a);
-    HIP_CHECK_RET(hipGetLastError());
+    for (int tb = 0; tb < KS * KS; tb += (KS == 7 ? 7 : KS * KS)) {     // 7x7: one launch per kernel row
+        a.tap_begin = tb;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), LDS, st, a);
+        HIP_CHECK_RET(hipGetLastError());
+    }
     return VSR_OK;
 }
 
@@ -584,7 +590,13 @@ extern "C" int vsr_debug_read_wgrad_stamps(unsigned long long* host_out) {
     X(3, 64, false, 64, false)        /* trunk / upsample / conv_last.0 */ \
     X(3, 16, true, 64, false)         /* stem, LR-frame part (conv.py:97) ; cleaner stem */ \
     X(3, 64, false, 16, true)         /* conv_last.2 (dY = planar SR cotangent) */ \
-    X(1, 64, false, 64, false)        /* point_conv halves */
+    X(1, 64, false, 64, false)        /* point_conv halves */ \
+    X(7, 16, false, 32, false)        /* SPyNet (train_flow): 8->32 */ \
+    X(7, 32, false, 64, false)        /* 32->64 */ \
+    X(7, 64, false, 32, false)        /* 64->32 (bf16; fp32 runs it as two 32-channel halves: LDS) */ \
+    X(7, 32, false, 32, false)        \
+    X(7, 32, false, 16, false)        /* 32->16 */ \
+    X(7, 16, false, 16, false)        /* 16->2 (dY = masked flow gradient, 16-channel padded) */
 
 // slab layout helper shared with the engine
 void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride) {
@@ -606,7 +618,10 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
 #define X(KS, CX, XP, COUT, DP)                                                                        \
     if (ks == KS && cx == CX && (x_planar != 0) == XP && cout == COUT && (dy_planar != 0) == DP) {    \
         if (dtype == VSR_BF16) return launch_wgrad_inst<bf16_t, KS, CX, XP, COUT, DP>(a, nwg, st);    \
-        if (dtype == VSR_F32) return launch_wgrad_inst<float, KS, CX, XP, COUT, DP>(a, nwg, st);      \
+        if (dtype == VSR_F32) {                                                                       \
+            if constexpr (KS == 7 && CX == 64) return VSR_ERR_UNSUPPORTED;                             \
+            else return launch_wgrad_inst<float, KS, CX, XP, COUT, DP>(a, nwg, st);                   \
+        }                                                                                             \
         return VSR_ERR_BADARG;                                                                        \
     }
     VSR_WGRAD_SHAPES(X)

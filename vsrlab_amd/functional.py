@@ -111,32 +111,37 @@ class _FlowWarpFn(torch.autograd.Function):
         out = _pm_like(xin)
         flow_planar = _f32c(flow_planar)
         _lib.check(lib.vsr_flow_warp_fwd(dtype, _ptr(xin), _ptr(flow_planar), _ptr(out), n, h, w, cp, _stream()), "flow_warp_fwd")
-        ctx.save_for_backward(flow_planar)
+        ctx.save_for_backward(flow_planar, xin if ctx.needs_input_grad[1] else None)
         ctx.meta = (dtype, c, cp)
         return from_pixel_major(out, c)
 
     @staticmethod
     def backward(ctx, gout):
-        (flow_planar,) = ctx.saved_tensors
+        flow_planar, xin = ctx.saved_tensors
         dtype, c, cp = ctx.meta
         n, _, h, w = gout.shape
         lib = _lib.load()
         g = to_pixel_major(gout, dtype, cp)
-        acc = torch.zeros((n, h, w, cp), dtype=torch.float32, device=gout.device)      # plain [N][H][W][C] fp32 accumulator
-        _lib.check(lib.vsr_flow_warp_bwd(dtype, _ptr(g), _ptr(flow_planar), _ptr(acc), n, h, w, cp, _stream()), "flow_warp_bwd")
-        return acc[..., :c].permute(0, 3, 1, 2).contiguous(), None, None
+        gx = gflow = None
+        if ctx.needs_input_grad[0]:
+            acc = torch.zeros((n, h, w, cp), dtype=torch.float32, device=gout.device)  # plain [N][H][W][C] fp32 accumulator
+            _lib.check(lib.vsr_flow_warp_bwd(dtype, _ptr(g), _ptr(flow_planar), _ptr(acc), n, h, w, cp, _stream()), "flow_warp_bwd")
+            gx = acc[..., :c].permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[1]:
+            gflow = torch.empty((n, 2, h, w), dtype=torch.float32, device=gout.device)
+            _lib.check(lib.vsr_flow_warp_bwd_flow(dtype, _ptr(xin), _ptr(g), _ptr(flow_planar), _ptr(gflow), n, h, w, cp, _stream()),
+                       "flow_warp_bwd_flow")
+        return gx, gflow, None
 
 
 def flow_warp(x: torch.Tensor, flow: torch.Tensor, interpolation: str = "bilinear", padding_mode: str = "zeros",
               align_corners: bool = True, compute_dtype: Optional[str] = None) -> torch.Tensor:
     """Drop-in for the reference ``flow_warp(x, flow)``: ``flow`` is channels-last (N,H,W,2),
-    [...,0] = horizontal displacement in pixels.  Differentiable w.r.t. ``x``."""
+    [...,0] = horizontal displacement in pixels.  Differentiable w.r.t. ``x`` and ``flow``."""
     if interpolation != "bilinear" or padding_mode != "zeros" or not align_corners:
         raise NotImplementedError("HIP flow_warp implements the BasicVSR propagation case: bilinear, zeros padding, "
                                   "align_corners=True (border padding is fused inside the SPyNet kernels)")
     _require_gpu(x, flow)
-    if flow.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("gradient w.r.t. the flow (train_flow=True) is not on the HIP path yet")
     return _FlowWarpFn.apply(x, flow.permute(0, 3, 1, 2), resolve_dtype(compute_dtype))
 
 
@@ -216,23 +221,48 @@ def residual_conv(x, w1, b1, w2, b2, compute_dtype: Optional[str] = None):
 # --------------------------------------------------------------------------------------------- #
 # SPyNet forward (reference: vsr/models/RealBasicVSR/modules/spynet.py:69-93)
 # --------------------------------------------------------------------------------------------- #
+class _SpynetFn(torch.autograd.Function):
+    """flow = Spynet(ref, supp) with the parameter gradients on the HIP engine (ref / supp are not differentiated)."""
+
+    @staticmethod
+    def forward(ctx, ref, supp, dtype, need_bwd, *params):
+        n, _, h, w = ref.shape
+        lib = _lib.load()
+        ps = [_f32c(p) for p in params]
+        ws = torch.empty(lib.vsr_spynet_workspace_bytes(n, h, w, dtype, int(need_bwd)), dtype=torch.uint8, device=ref.device)
+        flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=ref.device)
+        _lib.check(lib.vsr_spynet_forward(n, h, w, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(ref)), _ptr(_f32c(supp)), _ptr(flow),
+                                          _ptr(ws), ws.numel(), int(need_bwd), _stream()), "spynet_forward")
+        ctx.meta = (n, h, w, dtype, need_bwd)
+        ctx.ws = ws if need_bwd else None
+        ctx.ps = ps
+        return flow
+
+    @staticmethod
+    def backward(ctx, dflow):
+        n, h, w, dtype, need_bwd = ctx.meta
+        if not need_bwd:
+            raise RuntimeError("vsrlab_amd: backward through a SPyNet forward that ran without need_backward")
+        lib = _lib.load()
+        grads = [torch.zeros_like(p) if k < 60 else None for k, p in enumerate(ctx.ps)]
+        _lib.check(lib.vsr_spynet_backward(n, h, w, dtype, _ptr_array(grads), len(grads), _ptr(_f32c(dflow)), _ptr(ctx.ws),
+                                           ctx.ws.numel(), _stream()), "spynet_backward")
+        ctx.ws = None
+        return (None, None, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + k]) else None
+                                                for k, g in enumerate(grads))
+
+
 def spynet_flow(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.Tensor,
                 compute_dtype: Optional[str] = None) -> torch.Tensor:
-    """``params``: the 62 Spynet tensors in state_dict order (60 conv tensors, mean, std)."""
+    """``params``: the 62 Spynet tensors in state_dict order (60 conv tensors, mean, std).  Differentiable w.r.t. the
+    60 conv tensors (train_flow, basicvsr.py:25-28); not w.r.t. the frames."""
     _require_gpu(ref, supp)
     if len(params) != 62:
         raise ValueError("expected the 62 tensors of Spynet.state_dict()")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        raise NotImplementedError("SPyNet backward (train_flow=True) is not on the HIP path yet; freeze it or use no_grad")
-    dtype = resolve_dtype(compute_dtype)
-    n, _, h, w = ref.shape
-    lib = _lib.load()
-    ps = [_f32c(p) for p in params]
-    ws = torch.empty(lib.vsr_spynet_workspace_bytes(n, h, w, dtype), dtype=torch.uint8, device=ref.device)
-    flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=ref.device)
-    _lib.check(lib.vsr_spynet_forward(n, h, w, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(ref)), _ptr(_f32c(supp)), _ptr(flow),
-                                      _ptr(ws), ws.numel(), _stream()), "spynet_forward")
-    return flow
+    if torch.is_grad_enabled() and (ref.requires_grad or supp.requires_grad):
+        raise NotImplementedError("gradient of SPyNet w.r.t. its input frames is not on the HIP path yet")
+    need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params[:60])
+    return _SpynetFn.apply(ref, supp, resolve_dtype(compute_dtype), need_bwd, *params)
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -306,9 +336,12 @@ class _BasicVSRFn(torch.autograd.Function):
         desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
         lib = _lib.load()
         ps = ctx.ps
+        # need_bwd == 2 (train_flow): the SPyNet conv weights / biases (everything but the trailing mean, std buffers)
+        # are differentiated too
+        n_diff = len(ps) - 2 if ctx.need_bwd == 2 else ctx.n_trainable
         grads: List[Optional[torch.Tensor]] = [
-            torch.zeros_like(p) if (k < ctx.n_trainable and ctx.needs_input_grad[5 + k]) else None for k, p in enumerate(ps)]
-        want_all = [g if g is not None else (torch.zeros_like(p) if k < ctx.n_trainable else None)
+            torch.zeros_like(p) if (k < n_diff and ctx.needs_input_grad[5 + k]) else None for k, p in enumerate(ps)]
+        want_all = [g if g is not None else (torch.zeros_like(p) if k < n_diff else None)
                     for k, (g, p) in enumerate(zip(grads, ps))]   # engine produces weight+bias grads together
         _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(want_all), len(ps), _ptr(ctx.lr32),
                                              _ptr(_f32c(dsr)), _ptr(ctx.ws.buf), ctx.ws.buf.numel(), _stream()),
@@ -321,7 +354,9 @@ class _BasicVSRFn(torch.autograd.Function):
 def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_trainable: int, mid_channels: int,
                      res_blocks: int, upscale: int, pool: WorkspacePool, compute_dtype: Optional[str] = None) -> torch.Tensor:
     """sr = BasicVSR(lrs) on the HIP engine.  ``params`` in state_dict order; the first
-    ``n_trainable`` are the non-SPyNet tensors (SPyNet is frozen: basicvsr.py:25-28)."""
+    ``n_trainable`` are the non-SPyNet tensors.  SPyNet is frozen unless ``train_flow`` (basicvsr.py:25-28): if any
+    of its conv parameters requires grad the engine also keeps SPyNet's activations and differentiates it
+    (need_backward = 2)."""
     _require_gpu(lrs)
     if lrs.dim() != 5 or lrs.shape[2] != 3:
         raise ValueError("lrs must be (n,t,3,h,w)")
@@ -330,7 +365,12 @@ def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_traina
     n, t, _, h, w = lrs.shape
     desc_tuple = (n, t, h, w, mid_channels, res_blocks, upscale, resolve_dtype(compute_dtype))
     # grad mode is off inside Function.forward, so decide here whether activations must be retained
-    need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params[:n_trainable])
+    need_bwd = 0
+    if torch.is_grad_enabled():
+        if t > 1 and any(p.requires_grad for p in params[n_trainable:]):
+            need_bwd = 2
+        elif any(p.requires_grad for p in params[:n_trainable]):
+            need_bwd = 1
     return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, need_bwd, *params)
 
 

@@ -58,8 +58,6 @@ class BasicVSR(nn.Module):
         return flow_forward, flow_backward
 
     def forward(self, lrs):
-        if self.train_flow and torch.is_grad_enabled() and any(p.requires_grad for p in self.spynet.parameters()):
-            raise NotImplementedError("train_flow=True needs the SPyNet backward, which is not on the HIP path yet")
         tensors, n_trainable = self._ordered_tensors()
         return VF.basicvsr_forward(lrs, tensors, n_trainable, self.mid_channels, self.res_blocks, self.upscale_factor,
                                    self._pool, self.compute_dtype)
