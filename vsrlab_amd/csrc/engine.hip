@@ -493,9 +493,10 @@ struct WG {   // one weight-gradient launch + reduction
         int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
         if (nwg > cap) nwg = (int)cap;
         if (nwg > 1) nwg &= ~1;
-        CK(vsr_launch_wgrad(c.dtype, ks, cx, xp, cout, dyp, a, nwg, c.st));
+        int nslabs = 0;
+        CK(vsr_launch_wgrad(c.dtype, ks, cx, xp, cout, dyp, a, nwg, &nslabs, c.st));
         if (!gw) return VSR_ERR_BADARG;
-        return vsr_launch_wgrad_reduce(a.slab, nwg, ks, cx, cout, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, 1, c.st);
+        return vsr_launch_wgrad_reduce(a.slab, nslabs, ks, cx, cout, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, 1, c.st);
     }
 };
 
@@ -949,8 +950,9 @@ int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float*
     a.slab = slab; a.slab_stride = stride;
     const int tiles = N * cdiv(H, 8) * cdiv(W, 32);
     const int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
-    CK(vsr_launch_wgrad(dtype, 3, 64, 0, 64, 0, a, nwg, st));
-    return vsr_launch_wgrad_reduce(slab, nwg, 3, 64, 64, C, C, gw, C, 0, 1, 0, gb, 0, st);
+    int nslabs = 0;
+    CK(vsr_launch_wgrad(dtype, 3, 64, 0, 64, 0, a, nwg, &nslabs, st));
+    return vsr_launch_wgrad_reduce(slab, nslabs, 3, 64, 64, C, C, gw, C, 0, 1, 0, gb, 0, st);
 }
 
 int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, long long numel, float eps, void* stream) {

@@ -6,7 +6,7 @@ int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar
                     const ConvArgs& a, hipStream_t st);
 void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride);
 int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar, const WgradArgs& a, int nwg,
-                     hipStream_t st);
+                     int* nslabs, hipStream_t st);      // *nslabs: partial slabs written (what the reduction sums)
 int vsr_launch_wgrad_reduce(const float* slab, int nwg, int ks, int cx, int cout, int cout_real, int cin_real, float* gw,
                             int I_total, int i_off, int o_mul, int o_add, float* gb, int accumulate, hipStream_t st);
 int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out, int N, int H, int W, int C,

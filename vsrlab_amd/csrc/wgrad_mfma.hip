@@ -540,15 +540,29 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
         for (int k = 0; k < 8; ++k) g_wg_stamps[(blockIdx.x * 8 + wave) * 8 + k] = wst[k];
 #endif
 
-    // ---- partial slabs: one per (workgroup, row-half): [tap][64][64] then [64] bias sums ----
-    float* slab = a.slab + (long long)(blockIdx.x * 2 + kh) * a.slab_stride;
+    // ---- ONE partial slab per workgroup: [tap][64][64] then [64] bias sums.  The two row-halves (waves kh = 0 / 1 of
+    // the same (cb, ib)) are summed through LDS first: half the slab traffic here and in the reduction. ----
+    __syncthreads();                                           // the tile buffers are free
+    float* xch = reinterpret_cast<float*>(smem);               // [4 pairs][144][64 lanes] fp32 = 147,456 B
+    const int pair = wave & 3;
+    if (kh == 1) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            slab[((long long)tap * 64 + co) * 64 + ib * 32 + l31] = acc[tap][r];
-        }
+            for (int r = 0; r < 16; ++r) xch[((pair * 144) + tap * 16 + r) * 64 + lane] = acc[tap][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[((long long)tap * 64 + co) * 64 + ib * 32 + l31] = acc[tap][r] + xch[((pair * 144) + tap * 16 + r) * 64 + lane];
+            }
+    }
+    __syncthreads();                                           // xch consumed before `red` reuses the space
     float* red = reinterpret_cast<float*>(smem);               // [512][8]
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
@@ -557,12 +571,11 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
         float s = 0.f;
         const int c = tid >> 3, j = tid & 7;                   // thread t summed chunk (t & 7)
         for (int t = c; t < DNT; t += 8) s += red[t * 8 + j];
-        a.slab[(long long)(blockIdx.x * 2) * a.slab_stride + 9 * 64 * 64 + tid] = s;
-        a.slab[(long long)(blockIdx.x * 2 + 1) * a.slab_stride + 9 * 64 * 64 + tid] = 0.f;
+        a.slab[(long long)blockIdx.x * a.slab_stride + 9 * 64 * 64 + tid] = s;
     }
 }
 
-int launch_wgrad_dma(const WgradArgs& a0, int nslabs, hipStream_t st) {
+int launch_wgrad_dma(const WgradArgs& a0, int nwg, hipStream_t st) {     // nwg workgroups = nwg slabs
     constexpr int LDS = 2 * DSET;                              // 163,840: all of a CU's LDS
     static bool attr_set = false;
     if (!attr_set) {
@@ -573,7 +586,7 @@ int launch_wgrad_dma(const WgradArgs& a0, int nslabs, hipStream_t st) {
     WgradArgs a = a0;
     a.ntiles_x = cdiv(a.W, TW);
     a.ntiles_y = cdiv(a.H, TH);
-    hipLaunchKernelGGL(wgrad3x3_c64_dma_kernel, dim3(nslabs / 2), dim3(DNT), LDS, st, a);
+    hipLaunchKernelGGL(wgrad3x3_c64_dma_kernel, dim3(nwg), dim3(DNT), LDS, st, a);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
@@ -607,13 +620,16 @@ void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* st
 }
 
 int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar,
-                     const WgradArgs& a, int nwg, hipStream_t st) {
-    if (a.nseg < 1 || a.nseg > VSR_WG_MAXSEG || nwg < 1) return VSR_ERR_BADARG;
+                     const WgradArgs& a, int nwg, int* nslabs, hipStream_t st) {
+    if (a.nseg < 1 || a.nseg > VSR_WG_MAXSEG || nwg < 1 || !nslabs) return VSR_ERR_BADARG;
+    *nslabs = nwg;
     {   // hot shape: LDS-DMA double-buffered kernel (needs an even slab count: 2 row-halves per workgroup)
         static int force_generic = -1;
         if (force_generic < 0) { const char* e = getenv("VSRLAB_AMD_GENERIC_WGRAD"); force_generic = (e && e[0] == '1') ? 1 : 0; }
-        if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2 && nwg % 2 == 0)
-            return launch_wgrad_dma(a, nwg, st);
+        if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2) {
+            *nslabs = nwg / 2;                                 // one 512-thread workgroup per CU, one slab each
+            return launch_wgrad_dma(a, nwg / 2, st);
+        }
     }
 #define X(KS, CX, XP, COUT, DP)                                                                        \
     if (ks == KS && cx == CX && (x_planar != 0) == XP && cout == COUT && (dy_planar != 0) == DP) {    \

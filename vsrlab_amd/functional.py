@@ -339,10 +339,16 @@ class _BasicVSRFn(torch.autograd.Function):
         # need_bwd == 2 (train_flow): the SPyNet conv weights / biases (everything but the trailing mean, std buffers)
         # are differentiated too
         n_diff = len(ps) - 2 if ctx.need_bwd == 2 else ctx.n_trainable
+        # one zero-filled arena for all gradients (a fill kernel per tensor costs ~1 ms per step at 254 tensors);
+        # the engine produces weight and bias gradients together, so every differentiated tensor gets a slot
+        sizes = [p.numel() if k < n_diff else 0 for k, p in enumerate(ps)]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + ((sz + 63) // 64) * 64)          # 256-byte aligned slots
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dsr.device)
+        want_all = [flat[offs[k]:offs[k] + sizes[k]].view(p.shape) if k < n_diff else None for k, p in enumerate(ps)]
         grads: List[Optional[torch.Tensor]] = [
-            torch.zeros_like(p) if (k < n_diff and ctx.needs_input_grad[5 + k]) else None for k, p in enumerate(ps)]
-        want_all = [g if g is not None else (torch.zeros_like(p) if k < n_diff else None)
-                    for k, (g, p) in enumerate(zip(grads, ps))]   # engine produces weight+bias grads together
+            want_all[k] if (k < n_diff and ctx.needs_input_grad[5 + k]) else None for k in range(len(ps))]
         _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(want_all), len(ps), _ptr(ctx.lr32),
                                              _ptr(_f32c(dsr)), _ptr(ctx.ws.buf), ctx.ws.buf.numel(), _stream()),
                    "basicvsr_backward")
