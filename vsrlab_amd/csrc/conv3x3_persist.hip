@@ -98,7 +98,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     const int z = blockIdx.y;
     const int ntx = cdiv(a.W, PTW), nty = cdiv(a.H, PTH);
     const int total = a.N * ntx * nty;
-    const int WSs = pm_ws(a.W), WSd = pm_ws(a.Wd);
+    const int WSs = pm_ws(a.Ws), WSd = pm_ws(a.Wd);           // source / destination images may be larger than the view
 
     // bias of this z as fp32 in LDS: the accumulators of every tile start from it (32 fewer live registers
     // than carrying it, which is what lets two waves share a SIMD)
@@ -116,13 +116,15 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         const int idx = (w4 + 4 * i) * 64 + lane;           // LDS slot = [row ty][chunk c][34 pixels tx] x 16 B
         const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
         const int c = rem / PTWH, tx = rem - c * PTWH;
-        const int dx = tx - 1;
-        rel[i] = ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+        // view pixel (ty-1, tx-1) is source pixel (v*in_step + src_o): in_step 2 = one pixel-shuffle phase of a
+        // twice-as-large tensor (the data gradient of conv3x3 + PixelShuffle, one launch per phase)
+        const int dx = (tx - 1) * a.in_step + a.src_ox[0];
+        rel[i] = (((((ty - 1) * a.in_step + a.src_oy[0]) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
     }
     auto issue = [&](int tile, int buf) {
         int n, ty0, tx0;
         tile_coords(tile, ntx, nty, n, ty0, tx0);
-        const char* org = src + ((long long)n * a.src_nstride[0] + pm_off(ty0, tx0, 0, a.W, 64)) * 2;
+        const char* org = src + ((long long)n * a.src_nstride[0] + pm_off(ty0 * a.in_step, tx0 * a.in_step, 0, a.Ws, 64)) * 2;
         char* dstb = lds_t + buf * IN_BYTES;
         if (ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W) {          // interior tile (wave-uniform)
 #pragma unroll
@@ -359,7 +361,7 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     for (int z = 0; z < a.nz; ++z) { res = res || a.res[z]; aux = aux || a.aux[z]; }
     for (int z = 0; z < a.nz; ++z) if ((res && !a.res[z]) || (aux && !a.aux[z])) return VSR_ERR_UNSUPPORTED;
     const int mask = aux ? a.mask_mode : MASK_NONE;
-    if (pm_image_elems(PTHH + 2, a.W, 64) * 2 > 0x7fffffffLL || pm_image_elems(2 * PTH + 2, a.Wd, 64) > 0x7fffffffLL)
+    if (pm_image_elems((PTHH + 2) * a.in_step, a.Ws, 64) * 2 > 0x7fffffffLL || pm_image_elems(2 * PTH + 2, a.Wd, 64) > 0x7fffffffLL)
         return VSR_ERR_UNSUPPORTED;                                                  // in-tile offsets are 32-bit
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
     PERSIST_CASE(ACT_RELU, false, MASK_NONE)     // conv1 of a ResidualConv

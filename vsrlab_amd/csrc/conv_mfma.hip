@@ -393,7 +393,9 @@ int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar
     if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.nz < 1 || a.nz > VSR_MAX_Z) return VSR_ERR_BADARG;
     // the hot shape has its own persistent, weights-resident kernel (conv3x3_persist.hip)
     if (dtype == VSR_BF16 && ks == 3 && nsrc == 1 && ca == 64 && cb == 64 && !last_planar && cout_t == 64 && epi == EPI_NHWC &&
-        a.in_step == 1 && a.src_oy[0] == 0 && a.src_ox[0] == 0 && a.Hs == a.H && a.Ws == a.W && a.CD == 64 && a.cout_real == 64 &&
+        ((a.in_step == 1 && a.src_oy[0] == 0 && a.src_ox[0] == 0 && a.Hs == a.H && a.Ws == a.W) ||
+         (a.in_step == 2 && a.Hs == 2 * a.H && a.Ws == 2 * a.W && (unsigned)a.src_oy[0] < 2u && (unsigned)a.src_ox[0] < 2u)) &&
+        a.CD == 64 && a.cout_real == 64 &&
         a.src[0] != nullptr && !vsr_force_generic_conv()) {
         static int num_cus = 0;
         if (num_cus == 0) {
