@@ -20,8 +20,10 @@ def main():
     dev = torch.device("cuda:0")
     x = torch.randn(1, h, (w + 31) // 32, 8, 32, 8, device=dev).to(torch.bfloat16)
     r = torch.randn(1, h, (w + 31) // 32, 8, 32, 8, device=dev).to(torch.bfloat16)
+    if os.environ.get("BENCH_ZEROS") == "1":      # clock experiment: all-zero operands draw less power (MI355X_MICROARCH, DVFS give-back)
+        x.zero_(); r.zero_()
     y = torch.empty_like(x)
-    wgt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
+    wgt = torch.randn(64, 64, 3, 3, device=dev) * (0.0 if os.environ.get("BENCH_ZEROS") == "1" else 0.04)
     b = torch.zeros(64, device=dev)
     wpack = torch.empty(9 * 64 * 64, dtype=torch.bfloat16, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

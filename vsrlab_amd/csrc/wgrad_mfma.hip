@@ -575,6 +575,177 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArg
     }
 }
 
+// Two-workgroups-per-CU variant of the same kernel: 256 threads = 4 waves (cout-block, cin-block), each covering all 8
+// rows of a tile, ONE tile buffer set (80 KiB) per workgroup, so two workgroups share a CU.  A workgroup's memory
+// phase (LDS-DMA of its next tile, fully waited for) and matrix phase alternate; the two workgroups of a CU drift
+// out of phase, so one's DMA runs beside the other's MFMAs -- the overlap that could not be had inside one
+// workgroup (see the comment at the DMA issue of wgrad3x3_c64_dma_kernel).
+constexpr int PNT2 = 256;
+__global__ __launch_bounds__(PNT2, 2) void wgrad3x3_c64_pair_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int cb = wave & 1, ib = wave >> 1;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+    const int tiles_per_img = a.ntiles_x * a.ntiles_y;
+    const int per_seg = a.N * tiles_per_img;
+    const int total = a.nseg * per_seg;
+    const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
+    constexpr int NPIECE = (DX_PIECES + DY_PIECES) / 4;           // 20 per wave
+    static_assert((DX_PIECES + DY_PIECES) % 4 == 0, "even split over 4 waves");
+
+    auto issue = [&](int T) {
+        const int seg = T / per_seg;
+        const int r0 = T - seg * per_seg;
+        const int n = r0 / tiles_per_img;
+        const int r1 = r0 - n * tiles_per_img;
+        const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
+        const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
+        const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
+        const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, 0, a.Wx, 64) * 2;      // tx0*step: multiple of 32
+        const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, 0, a.Wy, 64) * 2;
+        const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;              // wave-uniform
+        // slot -> (row, chunk, pixel tx) -> source offset, computed here (the opaque lane id keeps hipcc from hoisting
+        // 20 offsets into registers that would live across the K loop); pad slots read the zero word
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const int piece = wave + 4 * i;
+            const bool isx = piece < DX_PIECES;
+            const char* src;
+            bool valid;
+            if (isx) {
+                const int idx = piece * 64 + lane_o;
+                const int row = idx / (8 * XS), rem = idx - row * (8 * XS);
+                const int c = rem / XS, tx = rem - c * XS;
+                const int dx = (tx - 1) * a.x_step + a.x_ox;
+                src = xo + (((((row - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+                valid = tx < TW + 2;
+                if (!interior) {
+                    const int vy = ty0 + row - 1, vx = tx0 + tx - 1;
+                    valid = valid && vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+                }
+            } else {
+                const int idx = (piece - DX_PIECES) * 64 + lane_o;
+                const int row = idx / (8 * YS), rem = idx - row * (8 * YS);
+                const int c = rem / YS, tx = rem - c * YS;
+                const int dx = tx * a.dy_step + a.dy_ox;
+                src = yo + ((((row * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+                valid = tx < TW;
+                if (!interior) valid = valid && ty0 + row < a.H && tx0 + tx < a.W;
+            }
+            if (!valid) src = zsrc;
+            char* dst = isx ? smem + piece * 1024 : smem + DXB + (piece - DX_PIECES) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    // transposing-read addresses: lane 4q+p of a 16-lane group supplies row (= pixel) q, columns (= channels) 4p..4p+3
+    const int g2 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+    const int chy = cb * 32 + 16 * g2 + p4, chx = ib * 32 + 16 * g2 + p4;
+    const int ybase = (chy >> 3) * (YS * 16) + (8 * h + q4) * 16 + (chy & 7) * 2;
+    const int xbase = (chx >> 3) * (XS * 16) + (8 * h + q4) * 16 + (chx & 7) * 2;
+    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
+    for (int T = walk.first; T < walk.end; T += walk.stride) {
+        __syncthreads();                                       // everybody has finished reading the buffer
+        issue(T);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // the tile has landed (everybody's pieces)
+        const char* lx = smem;
+        const char* ly = smem + DXB;
+        // bias partial sums: this thread's channel chunk (tid & 7) of 8 pixels of the dY tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = (tid >> 3) + 32 * i;
+            chunk_sum(*reinterpret_cast<const uint4*>(ly + (p >> 5) * YROW + (tid & 7) * (YS * 16) + (p & 31) * 16), bsum);
+        }
+#pragma unroll 1
+        for (int r2 = 0; r2 < 4; ++r2) {         // 4 passes of 2 tile rows; 144 accumulators: keep the body small
+            typedef union { s16x4_t s[2]; bf16x8_t b; } frag_u;
+            frag_u A[2], B[3][3];
+            const char* lyr = ly + ybase + (r2 * 2) * YROW;
+            const char* lxr = lx + xbase + (r2 * 2) * XROW;
+            auto loadA = [&](int ks, frag_u& f) {
+                const char* pa = lyr + (ks >> 1) * YROW + (ks & 1) * 256;
+                f.s[0] = tr_read(pa);
+                f.s[1] = tr_read(pa + 64);
+            };
+            auto loadB = [&](int g, frag_u* f) {
+                const int ks = g / 3, ky = g - 3 * ks, rr = ks >> 1, half = ks & 1;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const char* pb = lxr + (rr + ky) * XROW + (half * 16 + kx) * 16;
+                    f[kx].s[0] = tr_read(pb);
+                    f[kx].s[1] = tr_read(pb + 64);
+                }
+            };
+            loadA(0, A[0]);
+            loadB(0, B[0]);
+            loadB(1, B[1]);
+#define WG_GROUP(g)                                                                                                        \
+            {                                                                                                              \
+                constexpr int ks = (g) / 3, ky = (g) - 3 * ks;                                                             \
+                if (ky == 0 && ks + 1 < 4) loadA(ks + 1, A[(ks + 1) & 1]);                                                 \
+                if ((g) + 2 < 12) loadB((g) + 2, B[((g) + 2) % 3]);                                                        \
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                           \
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1].b, B[(g) % 3][kx].b, acc[ky * 3 + kx], 0, 0, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, ((g) + 2 < 12 ? 6 : 0) + ((ky == 0 && ks + 1 < 4) ? 2 : 0), 0); \
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                         \
+            }
+            WG_GROUP(0) WG_GROUP(1) WG_GROUP(2) WG_GROUP(3) WG_GROUP(4) WG_GROUP(5)
+            WG_GROUP(6) WG_GROUP(7) WG_GROUP(8) WG_GROUP(9) WG_GROUP(10) WG_GROUP(11)
+#undef WG_GROUP
+        }
+    }
+
+    // ---- one partial slab per workgroup: [tap][64][64] then [64] bias sums ----
+    float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            slab[((long long)tap * 64 + co) * 64 + ib * 32 + l31] = acc[tap][r];
+        }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);               // [256][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        const int c = tid >> 3, j = tid & 7;                   // thread t summed chunk (t & 7)
+        for (int t = c; t < PNT2; t += 8) s += red[t * 8 + j];
+        slab[9 * 64 * 64 + tid] = s;
+    }
+}
+
+int launch_wgrad_pair(const WgradArgs& a0, int nwg, hipStream_t st) {     // nwg workgroups (2 per CU) = nwg slabs
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_c64_pair_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, DSET));
+        attr_set = true;
+    }
+    WgradArgs a = a0;
+    a.ntiles_x = cdiv(a.W, TW);
+    a.ntiles_y = cdiv(a.H, TH);
+    hipLaunchKernelGGL(wgrad3x3_c64_pair_kernel, dim3(nwg), dim3(PNT2), DSET, st, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
 int launch_wgrad_dma(const WgradArgs& a0, int nwg, hipStream_t st) {     // nwg workgroups = nwg slabs
     constexpr int LDS = 2 * DSET;                              // 163,840: all of a CU's LDS
     static bool attr_set = false;
@@ -626,7 +797,10 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
     {   // hot shape: LDS-DMA double-buffered kernel (needs an even slab count: 2 row-halves per workgroup)
         static int force_generic = -1;
         if (force_generic < 0) { const char* e = getenv("VSRLAB_AMD_GENERIC_WGRAD"); force_generic = (e && e[0] == '1') ? 1 : 0; }
+        static int pair = -1;
+        if (pair < 0) { const char* e = getenv("VSRLAB_AMD_WGRAD_PAIR"); pair = (e && e[0] == '1') ? 1 : 0; }
         if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2) {
+            if (pair) return launch_wgrad_pair(a, nwg, st);    // two 256-thread workgroups per CU, one slab each
             *nslabs = nwg / 2;                                 // one 512-thread workgroup per CU, one slab each
             return launch_wgrad_dma(a, nwg / 2, st);
         }
