@@ -72,9 +72,12 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
  * (need_backward >= 1).  grads[k] (same order/shape as params; NULL = not wanted) are ACCUMULATED
  * into (+=).  SPyNet entries: all NULL = frozen flow net; otherwise the forward must have run with
  * need_backward = 2 and all 60 conv tensors get their gradient (flow gradient of the propagation
- * warps, spynet.py:95-106, then SPyNet's own backward, spynet.py:38-93).                         */
+ * warps, spynet.py:95-106, then SPyNet's own backward, spynet.py:38-93).
+ * dlrs (n,t,3,h,w) fp32 or NULL: the gradient w.r.t. the input clip is WRITTEN here (what RealBasicVSR's
+ * pre-clean stack receives): bilinear x4 skip + the stems' LR channels + the flows through SPyNet's image
+ * pyramid; also needs need_backward = 2.                                                        */
 int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads,
-                          int nparams, const float* lrs, const float* dsr, void* workspace,
+                          int nparams, const float* lrs, const float* dsr, float* dlrs, void* workspace,
                           size_t workspace_bytes, void* stream);
 
 /* Copies the optical flows computed by the last forward: (n,t-1,2,h,w) each

@@ -185,9 +185,32 @@ def trainflow():
     print("basicvsr_m64_rb3_trainflow", {k: v.shape for k, v in out.items()})
 
 
+def lrgrad():
+    """Gradient of BasicVSR w.r.t. its input clip (what RealBasicVSR's pre-clean stack receives, realbasicvsr.py:11-15):
+    through the stem's LR channels, the bilinear x4 skip (basicvsr.py:22,82), the propagation warps' flows and SPyNet's
+    image pyramid (spynet.py:38-93, frozen weights)."""
+    torch.set_num_threads(8)
+    basicvsr, spynet, realbasicvsr, conv, upsampling = import_reference()
+    mid, blocks, shape = 64, 3, (2, 3, 3, 24, 40)               # same clip / weights / cotangent as basicvsr_m64_rb3
+    m = load_keyed(basicvsr.BasicVSR(mid, blocks, 4, False, False)).double()
+    lrs = rand(10, *shape).double().requires_grad_(True)
+    n, t, _, h, w = shape
+    sr = m(lrs)
+    cot = rand(13, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1).double()
+    torch.mean(sr * cot).backward()
+    named = dict(m.named_parameters())
+    out = {"grad_lrs": lrs.grad.detach().numpy().astype(np.float64),
+           "grad__conv_last__2__weight": named["conv_last.2.weight"].grad.detach().numpy().astype(np.float64),
+           "seed_lr": np.asarray(10), "seed_cot": np.asarray(13)}
+    np.savez_compressed(os.path.join(HERE, "basicvsr_m64_rb3_lrgrad.npz"), **out)
+    print("basicvsr_m64_rb3_lrgrad", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "trainflow":
-        trainflow()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "main"):
         main()
+    if which in ("all", "trainflow"):
         trainflow()
+    if which in ("all", "lrgrad"):
+        lrgrad()

@@ -323,6 +323,41 @@ def test_basicvsr_train_flow_vs_golden():
     assert not bad, bad
 
 
+def test_basicvsr_input_gradient_vs_golden():
+    """d mean(sr*cot) / d lrs (what RealBasicVSR's pre-clean stack receives, realbasicvsr.py:11-15) against the
+    reference's fp64 gradient: bilinear x4 skip + the stems' LR channels + the flows through SPyNet's image pyramid
+    (frozen SPyNet weights).  fp32 build; also t = 1 (no flow path)."""
+    import numpy as np
+    from helpers import GOLDEN
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    dev = _gpu()
+    with np.load(os.path.join(GOLDEN, "basicvsr_m64_rb3_lrgrad.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    shape = (2, 3, 3, 24, 40)
+    n, t, _, h, w = shape
+    m = BasicVSR(64, 3, 4, False, False)
+    m.load_state_dict(O.keyed_state_dict(O.basicvsr_param_shapes(64, 3, 4)), strict=True)
+    m = m.to(dev)
+    m.compute_dtype = "fp32"
+    lrs = rand(int(g["seed_lr"]), *shape).to(dev).requires_grad_(True)
+    cot = rand(int(g["seed_cot"]), n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
+    torch.mean(m(lrs) * cot.to(dev)).backward()
+    ref = torch.from_numpy(g["grad_lrs"])
+    # the SPyNet part carries the fp32 ReLU-mask noise of test_basicvsr_train_flow_vs_golden; the skip and stem parts are exact
+    assert rel_l2(lrs.grad, ref) < 2e-2, rel_l2(lrs.grad, ref)
+    assert rel_l2(m.conv_last[2].weight.grad, torch.from_numpy(g["grad__conv_last__2__weight"])) < 1e-4
+    assert not any(p.grad is not None for p in m.spynet.parameters())
+    # single frame: no flow, the gradient is the skip + stem parts only -> sharp comparison with the oracle
+    sd = {k: v.double() for k, v in O.keyed_state_dict(O.basicvsr_param_shapes(64, 3, 4)).items()}
+    l1 = rand(51, 1, 1, 3, 20, 36)
+    c1 = rand(52, 1, 1, 3, 80, 144, lo=-1, hi=1)
+    lg = l1.clone().to(dev).requires_grad_(True)
+    torch.mean(m(lg) * c1.to(dev)).backward()
+    lo = l1.clone().double().requires_grad_(True)
+    torch.mean(O.basicvsr_forward(sd, lo) * c1.double()).backward()
+    assert rel_l2(lg.grad, lo.grad) < 1e-4, rel_l2(lg.grad, lo.grad)
+
+
 _C1 = {}
 
 

@@ -27,7 +27,7 @@ _SIGNATURES = {
     "vsr_basicvsr_num_params": (c_int, [ctypes.POINTER(BasicVSRDesc)]),
     "vsr_basicvsr_workspace_bytes": (c_size_t, [ctypes.POINTER(BasicVSRDesc), c_int]),
     "vsr_basicvsr_forward": (c_int, [ctypes.POINTER(BasicVSRDesc), _P, c_int, _P, _P, _P, c_size_t, c_int, _P]),
-    "vsr_basicvsr_backward": (c_int, [ctypes.POINTER(BasicVSRDesc), _P, _P, c_int, _P, _P, _P, c_size_t, _P]),
+    "vsr_basicvsr_backward": (c_int, [ctypes.POINTER(BasicVSRDesc), _P, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "vsr_basicvsr_get_flows": (c_int, [ctypes.POINTER(BasicVSRDesc), _P, _P, _P, _P]),
     "vsr_spynet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "vsr_spynet_forward": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, c_int, _P]),

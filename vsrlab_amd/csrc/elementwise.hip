@@ -369,10 +369,13 @@ __global__ void spynet_dres_kernel(const float* __restrict__ dflow, const float*
 //   g = dflow_l (flow = flow_up + residue)  +  dx16[6..7] (flow_up is a network input)
 //     + d/d(flow_up) of the border-mode warp of the supporting frame, contracted with dx16[3..5]
 //   dflow_prev += 2 * bilinear_x2^T(g)          (atomics; dflow_prev is zeroed by the caller)
+//   dframes (optional, (F,3,h,w) fp32, zeroed by the caller): d ref += dx16[0..2];  d supp += warp^T(dx16[3..5])
+//   (atomics: a frame is the reference of one pair and the supporting frame of another)
 template <typename T>
 __global__ void spynet_prepare_bwd_kernel(const T* __restrict__ dx16, const float* __restrict__ dflow_l,
                                           const float* __restrict__ frames, const float* __restrict__ flow_up,
-                                          float* __restrict__ dflow_prev, int n, int t, int P, int pair_mode, int h, int w) {
+                                          float* __restrict__ dflow_prev, float* __restrict__ dframes, int n, int t, int P,
+                                          int pair_mode, int h, int w) {
     const long long total = (long long)P * h * w;
     const int hp = h / 2, wp = w / 2;
     const float sy = hp > 1 ? (float)(hp - 1) / (float)(h - 1) : 0.f;
@@ -382,19 +385,20 @@ __global__ void spynet_prepare_bwd_kernel(const T* __restrict__ dx16, const floa
         const int x = (int)(idx % w);
         const int y = (int)((idx / w) % h);
         const int p = (int)(idx / hw);
-        int fsup;
+        int fsup, fref;
         if (pair_mode) {
-            fsup = P + p;
+            fref = p; fsup = P + p;
         } else {
             const int half = P / 2;
             const int q = p < half ? p : p - half;
             const int b = q / (t - 1), i = q % (t - 1);
+            fref = p < half ? b * t + i : b * t + i + 1;
             fsup = p < half ? b * t + i + 1 : b * t + i;
         }
         float d[8];
         unpack8(*reinterpret_cast<const typename EW<T>::chunk_t*>(dx16 + (long long)p * pm_image_elems(h, w, 16) + pm_off(y, x, 0, w, 16)), d);
-        const float fu0 = flow_up[((long long)p * 2 + 0) * hw + (long long)y * w + x];
-        const float fu1 = flow_up[((long long)p * 2 + 1) * hw + (long long)y * w + x];
+        const float fu0 = flow_up ? flow_up[((long long)p * 2 + 0) * hw + (long long)y * w + x] : 0.f;   // level 0: flow_up = 0
+        const float fu1 = flow_up ? flow_up[((long long)p * 2 + 1) * hw + (long long)y * w + x] : 0.f;
         float px = warp_coord((float)x, fu0, w), py = warp_coord((float)y, fu1, h);
         // border padding: clip_coordinates_set_grad (the gradient is 0 where the coordinate was clipped)
         const float mx = (px <= 0.f || px >= (float)(w - 1)) ? 0.f : 1.f;
@@ -417,6 +421,19 @@ __global__ void spynet_prepare_bwd_kernel(const T* __restrict__ dx16, const floa
             gx += d[3 + c] * (wy0 * (v01 - v00) + wy1 * (v11 - v10));
             gy += d[3 + c] * (wx0 * (v10 - v00) + wx1 * (v11 - v01));
         }
+        if (dframes) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                atomicAdd(dframes + ((long long)fref * 3 + c) * hw + (long long)y * w + x, d[c]);
+                float* sp = dframes + ((long long)fsup * 3 + c) * hw;
+                const float gv = d[3 + c];
+                atomicAdd(sp + y0 * w + x0, gv * wy0 * wx0);
+                if (x1ok) atomicAdd(sp + y0 * w + x1, gv * wy0 * wx1);
+                if (y1ok) atomicAdd(sp + y1 * w + x0, gv * wy1 * wx0);
+                if (x1ok && y1ok) atomicAdd(sp + y1 * w + x1, gv * wy1 * wx1);
+            }
+        }
+        if (!dflow_prev) continue;                          // level 0: nothing below
         float g[2];
         g[0] = d[6] + (w > 1 ? gx * mx : 0.f);
         g[1] = d[7] + (h > 1 ? gy * my : 0.f);
@@ -457,6 +474,81 @@ __global__ void flow_out_bwd_kernel(const float* __restrict__ dout, float* __res
         atomicAdd(ip + y0 * wu + x1, v * (1.f - ly) * lx);
         atomicAdd(ip + y1 * wu + x0, v * ly * (1.f - lx));
         atomicAdd(ip + y1 * wu + x1, v * ly * lx);
+    }
+}
+
+// pyramid adjoints (spynet.py:44-45, 72-80): dfine += 0.25 * dcoarse[y/2][x/2]   (avg_pool2d backward)
+__global__ void avgpool2_bwd_add_kernel(const float* __restrict__ dcoarse, float* __restrict__ dfine, long long planes, int h, int w) {
+    const int ho = h / 2, wo = w / 2;
+    const long long total = planes * h * w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const long long pl = idx / ((long long)w * h);
+        if ((y >> 1) < ho && (x >> 1) < wo) dfine[idx] += 0.25f * dcoarse[pl * ho * wo + (long long)(y >> 1) * wo + (x >> 1)];
+    }
+}
+
+// dframes (F,3,h,w) += resize^T(dnorm (F,3,hu,wu)) / std   (backward of resize_norm_kernel; atomics)
+__global__ void resize_norm_bwd_kernel(const float* __restrict__ dnorm, float* __restrict__ dframes, const float* __restrict__ std,
+                                       int F, int h, int w, int hu, int wu) {
+    const long long total = (long long)F * 3 * hu * wu;
+    const float sy = (float)h / (float)hu, sx = (float)w / (float)wu;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % wu);
+        const int y = (int)((idx / wu) % hu);
+        const int c = (int)((idx / ((long long)wu * hu)) % 3);
+        const long long f = idx / ((long long)wu * hu * 3);
+        int y0, y1, x0, x1; float ly, lx;
+        src_index(y, sy, h, false, y0, y1, ly);
+        src_index(x, sx, w, false, x0, x1, lx);
+        float* p = dframes + (f * 3 + c) * (long long)h * w;
+        const float v = dnorm[idx] / std[c];
+        atomicAdd(p + y0 * w + x0, v * (1.f - ly) * (1.f - lx));
+        atomicAdd(p + y0 * w + x1, v * (1.f - ly) * lx);
+        atomicAdd(p + y1 * w + x0, v * ly * (1.f - lx));
+        atomicAdd(p + y1 * w + x1, v * ly * lx);
+    }
+}
+
+// dlr (F,3,h,w) = bilinear_x4^T(dsr (F,3,4h,4w))   (the `+ upscale(lr_i)` skip, basicvsr.py:22,82), as a gather: LR pixel
+// y receives from the HR rows whose two source rows (align_corners=False, clamped at 0) include y
+__global__ void bilinear4_bwd_kernel(const float* __restrict__ dsr, float* __restrict__ dlr, long long planes, int h, int w) {
+    const long long total = planes * h * w;
+    const int H = 4 * h, W = 4 * w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const long long pl = idx / ((long long)w * h);
+        const float* sp = dsr + pl * H * W;
+        float wy[12], wx[12];
+        int Y0 = 4 * y - 4, X0 = 4 * x - 4;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int Y = Y0 + k, X = X0 + k;
+            wy[k] = 0.f; wx[k] = 0.f;
+            if (Y >= 0 && Y < H) {
+                float s = (Y + 0.5f) * 0.25f - 0.5f; s = s < 0.f ? 0.f : s;
+                const int i0 = (int)s; const int i1 = i0 + (i0 < h - 1 ? 1 : 0); const float l1 = s - (float)i0;
+                wy[k] = (i0 == y ? 1.f - l1 : 0.f) + (i1 == y ? l1 : 0.f);
+            }
+            if (X >= 0 && X < W) {
+                float s = (X + 0.5f) * 0.25f - 0.5f; s = s < 0.f ? 0.f : s;
+                const int i0 = (int)s; const int i1 = i0 + (i0 < w - 1 ? 1 : 0); const float l1 = s - (float)i0;
+                wx[k] = (i0 == x ? 1.f - l1 : 0.f) + (i1 == x ? l1 : 0.f);
+            }
+        }
+        float acc = 0.f;
+        for (int ky = 0; ky < 12; ++ky) {
+            if (wy[ky] == 0.f) continue;
+            const float* row = sp + (long long)(Y0 + ky) * W;
+            float r = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 12; ++kx)
+                if (wx[kx] != 0.f) r += wx[kx] * row[X0 + kx];
+            acc += wy[ky] * r;
+        }
+        dlr[idx] = acc;
     }
 }
 
@@ -586,14 +678,32 @@ int vsr_launch_spynet_dres(int dtype, const float* dflow, const float* res, void
 }
 
 int vsr_launch_spynet_prepare_bwd(int dtype, const void* dx16, const float* dflow_l, const float* frames, const float* flow_up,
-                                  float* dflow_prev, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(spynet_prepare_bwd_kernel<T>, dim3(grid_for((long long)P * h * w)), dim3(256), 0, st, (const T*)dx16, dflow_l, frames, flow_up, dflow_prev, n, t, P, pair_mode, h, w));
+                                  float* dflow_prev, float* dframes, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(spynet_prepare_bwd_kernel<T>, dim3(grid_for((long long)P * h * w)), dim3(256), 0, st, (const T*)dx16, dflow_l, frames, flow_up, dflow_prev, dframes, n, t, P, pair_mode, h, w));
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
 
 int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu, int h, int w, hipStream_t st) {
     hipLaunchKernelGGL(flow_out_bwd_kernel, dim3(grid_for((long long)P * 2 * h * w)), dim3(256), 0, st, dout, din, P, hu, wu, h, w);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_avgpool2_bwd_add(const float* dcoarse, float* dfine, long long planes, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(avgpool2_bwd_add_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, st, dcoarse, dfine, planes, h, w);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_resize_norm_bwd(const float* dnorm, float* dframes, const float* std, int F, int h, int w, int hu, int wu, hipStream_t st) {
+    hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3(grid_for((long long)F * 3 * hu * wu)), dim3(256), 0, st, dnorm, dframes, std, F, h, w, hu, wu);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(bilinear4_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, st, dsr, dlr, planes, h, w);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

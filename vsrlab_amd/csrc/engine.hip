@@ -43,6 +43,7 @@ struct SpyPlan {
     size_t sfup[6], sres[6];            // planar fp32 flow_up and residue (= ReLU(conv5)) per level
     size_t wpackd[6][NSPY];
     size_t gA, gB, dres, dfa, dfb;
+    size_t dpyr[6];                     // gradient of the normalised pyramid (input-frame gradient)
     void plan_save(Bump& b, int dtype) {
         save = true;
         const size_t es = esize(dtype);
@@ -58,6 +59,7 @@ struct SpyPlan {
         dres = b.take((size_t)P * pm_image_elems(hu, wu, 16) * es);
         dfa = b.take((size_t)P * 2 * hu * wu * 4);
         dfb = b.take((size_t)P * 2 * hu * wu * 4);
+        for (int l = 0; l < 6; ++l) dpyr[l] = b.take((size_t)F * 3 * (hu >> (5 - l)) * (wu >> (5 - l)) * 4);
     }
     void plan(Bump& b, int P_, int F_, int h_, int w_, int dtype) {
         P = P_; F = F_; h = h_; w = w_;
@@ -107,7 +109,8 @@ struct Plan {
     std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
     size_t S[2], dWp[2], slab[2];               // per direction / stream
     size_t G_C0, G_U1, G_U0, G_P;
-    size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow)
+    size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow / input gradient)
+    size_t stem_wd_lr[2];       // data-gradient weights of the stems' 3 LR input channels (input gradient)
     size_t total;
 
     size_t xoff(int dir, int i, int b) const { return X[dir][(size_t)i * (rb + 1) + b]; }
@@ -181,6 +184,9 @@ struct Plan {
         if (flowgrad && t > 1) {
             dflows = b.take((size_t)2 * n * (t - 1) * 2 * h * w * 4);
             spy.plan_save(b, dtype);
+        }
+        if (flowgrad) {
+            for (int dir = 0; dir < 2; ++dir) stem_wd_lr[dir] = b.take((size_t)9 * 32 * C * es);
         }
         total = b.off;
         return VSR_OK;
@@ -340,6 +346,7 @@ int pack_all(const Ctx& c, const Plan& p, const float* const* prm) {
         CK(c.pack(sw, p.stem_w[dir] + (size_t)9 * C * C * p.es, 9, C, 16, C, 3, C + 3, 0, 1, 0, 0));
         CK(c.pack_bias(prm[ix.stem_b(dir)], p.stem_b[dir], C));
         if (p.bwd) CK(c.pack(sw, p.stem_wd[dir], 9, C, C, C, C, C + 3, 3, 1, 0, 1));
+        if (p.flowgrad) CK(c.pack(sw, p.stem_wd_lr[dir], 9, 32, C, 3, C, C + 3, 0, 1, 0, 1));
         for (int k = 0; k < 2 * p.rb; ++k) {
             CK(c.pack(prm[ix.blk_w(dir, k)], p.blk_w[dir][k], 9, C, C, C, C, C, 0, 1, 0, 0));
             if (p.bwd) CK(c.pack(prm[ix.blk_w(dir, k)], p.blk_wd[dir][k], 9, C, C, C, C, C, 0, 1, 0, 1));
@@ -527,13 +534,17 @@ WgradArgs wg_base(int N, int H, int W) {
 
 // Backward of spynet_run for train_flow (spynet.py:38-93): dflows_out = d loss / d flows (P,2,h,w) ->
 // weight / bias gradients of the 6 x 5 convs (g[base_idx ...], OIHW fp32).  The frames are not differentiated.
+// dframes (optional): (F,3,h,w) fp32, ACCUMULATED into: the gradient w.r.t. the input frames (through the pyramid).
 int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, int n, int t, int pair_mode, float* const* g,
-                    int base_idx) {
+                    int base_idx, float* dframes = nullptr, const float* std = nullptr) {
     const WG wg{c};
     const int P = sp.P, hu = sp.hu, wu = sp.wu;
     size_t dcur = sp.dfa, dprev = sp.dfb;
     HIP_CHECK_RET(hipMemsetAsync(c.at(dcur), 0, (size_t)P * 2 * hu * wu * 4, c.st));
     CK(vsr_launch_flow_out_bwd(dflows_out, (float*)c.at(dcur), P, hu, wu, sp.h, sp.w, c.st));
+    if (dframes)
+        for (int l = 0; l < 6; ++l)
+            HIP_CHECK_RET(hipMemsetAsync(c.at(sp.dpyr[l]), 0, (size_t)sp.F * 3 * (hu >> (5 - l)) * (wu >> (5 - l)) * 4, c.st));
     for (int l = 5; l >= 0; --l) {
         const int hl = hu >> (5 - l), wl = wu >> (5 - l);
         // flow_l = flow_up + ReLU(conv5): dY of the last conv, as a 16-channel pixel-major tensor
@@ -541,8 +552,8 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
         size_t dy = sp.dres;
         for (int j = NSPY - 1; j >= 0; --j) {
             const int CI = SPY_CIP[j], CO = SPY_DK[j];
-            float* gw = g[base_idx + (l * NSPY + j) * 2];
-            float* gb = g[base_idx + (l * NSPY + j) * 2 + 1];
+            float* gw = g ? g[base_idx + (l * NSPY + j) * 2] : nullptr;
+            float* gb = g ? g[base_idx + (l * NSPY + j) * 2 + 1] : nullptr;
             if (gw || gb) {
                 // fp32, 64 input channels: two 32-channel halves (the 14x38-pixel fp32 tile of 64 channels exceeds LDS)
                 const int nhalf = (c.dtype == VSR_F32 && CI == 64) ? 2 : 1;
@@ -556,7 +567,7 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
                     CK(wg.run(7, cx, false, CO, false, a, SPY_CO[j], cin_real, gw, SPY_CI[j], hf * cx, 1, 0, hf == 0 ? gb : nullptr));
                 }
             }
-            if (j == 0 && l == 0) break;                   // level 0's input does not depend on anything differentiated
+            if (j == 0 && l == 0 && !dframes) break;       // level 0's input depends on the frames only
             // dX_j = dgrad(conv_j)(dY_j) (* ReLU'(X_j) for j > 0: X_j is the previous conv's ReLU output)
             const size_t dx = (dy == sp.gA) ? sp.gB : sp.gA;
             ConvArgs a = c.base(P, hl, wl);
@@ -567,12 +578,21 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
             CK(vsr_launch_conv(c.dtype, 7, 1, CO, CO, 0, SPY_DROWS[j], EPI_NHWC, a, c.st));
             dy = dx;
         }
-        if (l == 0) break;
+        float* dfr = dframes ? (float*)c.at(sp.dpyr[l]) : nullptr;
+        if (l == 0) {
+            if (dfr) CK(vsr_launch_spynet_prepare_bwd(c.dtype, c.at(dy), nullptr, c.fat(sp.pyr[0]), nullptr, nullptr, dfr, n, t, P, pair_mode, hl, wl, c.st));
+            break;
+        }
         // x16 = [ref | warp(supp, flow_up) | flow_up], flow_up = 2 * up(flow_{l-1}): everything that reaches flow_{l-1}
         HIP_CHECK_RET(hipMemsetAsync(c.at(dprev), 0, (size_t)P * 2 * (hl / 2) * (wl / 2) * 4, c.st));
-        CK(vsr_launch_spynet_prepare_bwd(c.dtype, c.at(dy), c.fat(dcur), c.fat(sp.pyr[l]), c.fat(sp.sfup[l]), (float*)c.at(dprev),
+        CK(vsr_launch_spynet_prepare_bwd(c.dtype, c.at(dy), c.fat(dcur), c.fat(sp.pyr[l]), c.fat(sp.sfup[l]), (float*)c.at(dprev), dfr,
                                          n, t, P, pair_mode, hl, wl, c.st));
         const size_t tmp = dcur; dcur = dprev; dprev = tmp;
+    }
+    if (dframes) {   // pyramid adjoint: avg_pool2d from fine to coarse (spynet.py:44-45), then the /32 resize + normalisation
+        for (int l = 1; l < 6; ++l)
+            CK(vsr_launch_avgpool2_bwd_add(c.fat(sp.dpyr[l - 1]), (float*)c.at(sp.dpyr[l]), (long long)sp.F * 3, hu >> (5 - l), wu >> (5 - l), c.st));
+        CK(vsr_launch_resize_norm_bwd(c.fat(sp.dpyr[5]), dframes, std, sp.F, sp.h, sp.w, hu, wu, c.st));
     }
     return VSR_OK;
 }
@@ -707,10 +727,11 @@ int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float
     return trunk_wgrads(c, p, dir, lrs, g);
 }
 
-int backward_impl(const Plan& p, const float* const* prm, float* const* g, const float* lrs, const float* dsr, char* ws,
-                  hipStream_t st) {
-    (void)prm;
+int backward_impl(const Plan& p, const float* const* prm, float* const* g, const float* lrs, const float* dsr, float* dlrs,
+                  char* ws, hipStream_t st) {
     const Ctx c{p, ws, st, p.dtype, 0};
+    // input gradient, part 1: the bilinear x4 skip (basicvsr.py:22,82) -- overwrites dlrs, everything else accumulates
+    if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st));
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
     CK(f.begin());
@@ -718,8 +739,18 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     CK(backward_chain(c, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
     CK(f.end());
-    if (p.flowgrad && p.t > 1)
-        CK(spynet_backward(c, p.spy, c.fat(p.dflows), p.n, p.t, 0, g, PIdx{p.rb}.spy_base()));
+    if (dlrs) {   // part 2: the stems' LR channels (conv.py:97 on cat([lr_i, feat])), both directions, every frame
+        for (int dir = 0; dir < 2; ++dir)
+            for (int i = 0; i < p.t; ++i) {
+                ConvArgs a = c.base(p.n, p.h, p.w);
+                a.src[0] = c.at(p.G0[dir][i]); a.wpack = c.at(p.stem_wd_lr[dir]); a.cout_real = 3;
+                float* d = dlrs + (size_t)i * 3 * p.h * p.w;
+                a.dst[0] = d; a.pres = d; a.dst_nstride = (long long)p.t * 3 * p.h * p.w;
+                CK(vsr_launch_conv(c.dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, c.st));
+            }
+    }
+    if (p.flowgrad && p.t > 1)   // part 3 (and train_flow): through the flows into SPyNet's parameters / image pyramid
+        CK(spynet_backward(c, p.spy, c.fat(p.dflows), p.n, p.t, 0, g, PIdx{p.rb}.spy_base(), dlrs, prm[PIdx{p.rb}.spy_std()]));
     return VSR_OK;
 }
 
@@ -765,17 +796,17 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
 }
 
 int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads, int nparams,
-                          const float* lrs, const float* dsr, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!d || !grads || !lrs || !dsr || !workspace) return VSR_ERR_BADARG;
+                          const float* lrs, const float* dsr, float* dlrs, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !params || !grads || !lrs || !dsr || !workspace) return VSR_ERR_BADARG;
     if (d->res_blocks < 1) return VSR_ERR_UNSUPPORTED;
     const PIdx ix{d->res_blocks};
     if (nparams != ix.count()) return VSR_ERR_BADARG;
-    bool flow = false;                                     // any SPyNet gradient wanted => the forward ran with need_backward = 2
+    bool flow = dlrs != nullptr;                           // input or SPyNet gradient wanted => the forward ran with need_backward = 2
     for (int k = ix.spy_base(); k < ix.spy_mean(); ++k) flow = flow || grads[k];
     Plan p;
     CK(p.build(*d, flow ? 2 : 1));
     if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
-    return backward_impl(p, params, grads, lrs, dsr, (char*)workspace, (hipStream_t)stream);
+    return backward_impl(p, params, grads, lrs, dsr, dlrs, (char*)workspace, (hipStream_t)stream);
 }
 
 int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, float* flow_forward, float* flow_backward, void* stream) {

@@ -26,7 +26,10 @@ int vsr_launch_warp_bwd_flow(int dtype, const void* in, const void* dout, const 
                              int C, long long flow_nstride, hipStream_t st);
 int vsr_launch_spynet_dres(int dtype, const float* dflow, const float* res, void* out, int P, int h, int w, hipStream_t st);
 int vsr_launch_spynet_prepare_bwd(int dtype, const void* dx16, const float* dflow_l, const float* frames, const float* flow_up,
-                                  float* dflow_prev, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st);
+                                  float* dflow_prev, float* dframes, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st);
+int vsr_launch_avgpool2_bwd_add(const float* dcoarse, float* dfine, long long planes, int h, int w, hipStream_t st);
+int vsr_launch_resize_norm_bwd(const float* dnorm, float* dframes, const float* std, int F, int h, int w, int hu, int wu, hipStream_t st);
+int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int h, int w, hipStream_t st);
 int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu, int h, int w, hipStream_t st);
 int vsr_launch_add_f32(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,

@@ -349,12 +349,13 @@ class _BasicVSRFn(torch.autograd.Function):
         want_all = [flat[offs[k]:offs[k] + sizes[k]].view(p.shape) if k < n_diff else None for k, p in enumerate(ps)]
         grads: List[Optional[torch.Tensor]] = [
             want_all[k] if (k < n_diff and ctx.needs_input_grad[5 + k]) else None for k in range(len(ps))]
+        dlrs = torch.empty_like(ctx.lr32) if ctx.needs_input_grad[0] else None      # gradient w.r.t. the clip (need_bwd == 2)
         _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(want_all), len(ps), _ptr(ctx.lr32),
-                                             _ptr(_f32c(dsr)), _ptr(ctx.ws.buf), ctx.ws.buf.numel(), _stream()),
+                                             _ptr(_f32c(dsr)), _ptr(dlrs), _ptr(ctx.ws.buf), ctx.ws.buf.numel(), _stream()),
                    "basicvsr_backward")
         ctx.ws.owner = None
         ctx.token = None
-        return (None, None, None, None, None) + tuple(grads)
+        return (dlrs, None, None, None, None) + tuple(grads)
 
 
 def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_trainable: int, mid_channels: int,
@@ -366,15 +367,13 @@ def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_traina
     _require_gpu(lrs)
     if lrs.dim() != 5 or lrs.shape[2] != 3:
         raise ValueError("lrs must be (n,t,3,h,w)")
-    if lrs.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("gradient w.r.t. the LR clip (RealBasicVSR pre-clean stack) is not on the HIP path yet")
     n, t, _, h, w = lrs.shape
     desc_tuple = (n, t, h, w, mid_channels, res_blocks, upscale, resolve_dtype(compute_dtype))
     # grad mode is off inside Function.forward, so decide here whether activations must be retained
     need_bwd = 0
     if torch.is_grad_enabled():
-        if t > 1 and any(p.requires_grad for p in params[n_trainable:]):
-            need_bwd = 2
+        if lrs.requires_grad or (t > 1 and any(p.requires_grad for p in params[n_trainable:])):
+            need_bwd = 2                                      # input-clip and / or SPyNet gradients: SPyNet's activations are kept
         elif any(p.requires_grad for p in params[:n_trainable]):
             need_bwd = 1
     return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, need_bwd, *params)
