@@ -102,10 +102,17 @@ int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int
  * the F = n*t frames (F,3,h,w) fp32 planar.  params (4 + 4*blocks tensors): resblock.conv.0.{weight,
  * bias}, resblock.res_block.{i}.conv1.{weight,bias}, conv2.{weight,bias} ..., conv.{weight,bias}.
  * lq is a fresh tensor (the reference updates lr in place: SURVEY.md appendix A3).             */
-size_t vsr_cleaner_workspace_bytes(int F, int h, int w, int blocks, int dtype);
+size_t vsr_cleaner_workspace_bytes(int F, int h, int w, int blocks, int steps, int dtype, int need_backward);
 int vsr_cleaner_forward(int F, int h, int w, int mid_channels, int blocks, int steps, int dtype,
                         const float* const* params, int nparams, const float* lr, float* lq,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, int need_backward, void* stream);
+/* Backward of the forward that last ran on `workspace` with need_backward = 1, for the cotangent dlq (F,3,h,w):
+ * grads[k] (same order/shape as params; NULL = not wanted, a bias needs its weight's entry) are ACCUMULATED
+ * into (the parameters are shared by the `steps` iterations); dlr (F,3,h,w) or NULL is written.  `lr` is the
+ * forward's input (its first step's stem weight gradient needs it).                                        */
+int vsr_cleaner_backward(int F, int h, int w, int mid_channels, int blocks, int steps, int dtype,
+                         float* const* grads, int nparams, const float* lr, const float* dlq, float* dlr,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- per-op entry points (pixel-major tensors) --------------------------------------------- */
 /* flow_warp, zeros padding (spynet.py:95-106): out[n,y,x,:] = bilinear(in[n], x+fx, y+fy)     */

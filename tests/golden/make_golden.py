@@ -206,8 +206,36 @@ def lrgrad():
     print("basicvsr_m64_rb3_lrgrad", {k: v.shape for k, v in out.items()})
 
 
+def realtrain():
+    """RealBasicVSR training gradients.  The reference's own backward raises in fp32 (`x += residues` overwrites a tensor
+    saved for backward, realbasicvsr.py:29); it runs under autocast, where the saved tensors are
+    the bf16 copies -- which is how the reference is trained (train.py:93).  So this fixture is the reference under CPU
+    autocast(bfloat16): a LOOSE pin (bf16 rounding) of the pre-clean stack's gradients; the sharp pin is the oracle."""
+    torch.set_num_threads(8)
+    basicvsr, spynet, realbasicvsr, conv, upsampling = import_reference()
+    m = load_keyed(realbasicvsr.RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2, pretrained_flow=False, train_flow=False))
+    shape = (1, 3, 3, 24, 40)
+    n, t, _, h, w = shape
+    lr = rand(14, *shape)
+    cot_sr = rand(15, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
+    cot_lq = rand(16, n, t, 3, h, w, lo=-1, hi=1)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        sr, lq = m(lr.clone())
+    (torch.mean(sr.float() * cot_sr) + torch.mean(lq.float() * cot_lq)).backward()
+    named = dict(m.named_parameters())
+    keys = ["cleaner.resblock.conv.0.weight", "cleaner.resblock.res_block.0.conv1.weight", "cleaner.resblock.res_block.1.conv2.weight",
+            "cleaner.conv.weight", "cleaner.conv.bias", "basicvsr.conv_last.2.weight", "basicvsr.backward_resblocks.conv.0.weight"]
+    out = {"grad__" + k.replace(".", "__"): named[k].grad.detach().float().numpy() for k in keys}
+    out.update(seed_lr=np.asarray(14), seed_cot_sr=np.asarray(15), seed_cot_lq=np.asarray(16),
+               sr=sr.detach().float().numpy(), lq=lq.detach().float().numpy())
+    np.savez_compressed(os.path.join(HERE, "realbasicvsr_m64_train_autocast.npz"), **out)
+    print("realbasicvsr_m64_train_autocast", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "realtrain"):
+        realtrain()
     if which in ("all", "main"):
         main()
     if which in ("all", "trainflow"):

@@ -36,3 +36,20 @@ def proj_vector(key, shape):
     import zlib
     g = torch.Generator().manual_seed(zlib.crc32(("proj:" + key).encode()) & 0x7fffffff)
     return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def realbasicvsr_shapes(mid, res_blocks, cleaning_blocks):
+    """state_dict key -> shape of RealBasicVSR(cleaning_blocks, mid_channels=mid, res_blocks=res_blocks)."""
+    from oracle import basicvsr_oracle as O
+    shapes = {"basicvsr." + k: s for k, s in O.basicvsr_param_shapes(mid, res_blocks, 4).items()}
+    shapes.update(O.cleaner_param_shapes(mid, cleaning_blocks))
+    return shapes
+
+
+def realbasicvsr_oracle_grads(sd64, lr, cot_sr, cot_lq):
+    """fp64 oracle: d [mean(sr*cot_sr) + mean(lq*cot_lq)] / d every trainable tensor (frozen SPyNet)."""
+    from oracle import basicvsr_oracle as O
+    leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "spynet" not in k) for k, v in sd64.items()}
+    sr, lq = O.realbasicvsr_forward(leaves, lr)
+    (torch.mean(sr * cot_sr) + torch.mean(lq * cot_lq)).backward()
+    return sr.detach(), lq.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}

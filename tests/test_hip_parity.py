@@ -358,6 +358,45 @@ def test_basicvsr_input_gradient_vs_golden():
     assert rel_l2(lg.grad, lo.grad) < 1e-4, rel_l2(lg.grad, lo.grad)
 
 
+def test_realbasicvsr_training_vs_oracle():
+    """sr, lq = RealBasicVSR(lr) with gradients of a two-term loss (core/utils.py:235-240 has one Charbonnier term on
+    each output) for EVERY trainable tensor: the pre-clean stack's backward (3 iterations sharing their weights), fed by
+    the gradient w.r.t. lq from BasicVSR.  fp32 build vs the fp64 oracle (itself pinned to the reference's autocast run
+    by tests/test_oracle_golden.py).  t = 3 carries SPyNet's fp32 mask noise in d lq; t = 1 has no flow path and is sharp."""
+    from helpers import realbasicvsr_shapes, realbasicvsr_oracle_grads
+    from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
+    dev = _gpu()
+    sd32 = O.keyed_state_dict(realbasicvsr_shapes(64, 2, 2))
+    m = RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2, pretrained_flow=False, train_flow=False)
+    m.load_state_dict(sd32, strict=True)
+    m = m.to(dev)
+    m.basicvsr.compute_dtype = "fp32"
+    os.environ["VSRLAB_AMD_DTYPE"] = "fp32"
+    try:
+        for shape, t_glob, t_worst in (((1, 3, 3, 24, 40), 2e-2, 1e-1), ((2, 1, 3, 20, 36), 1e-3, 1e-2)):
+            n, t, _, h, w = shape
+            lr = rand(14, *shape)
+            cot_sr = rand(15, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
+            cot_lq = rand(16, n, t, 3, h, w, lo=-1, hi=1)
+            m.zero_grad(set_to_none=True)
+            lin = lr.clone().to(dev)
+            sr, lq = m(lin)
+            assert torch.equal(lin.cpu(), lr)                       # the input is not modified (the reference overwrites it)
+            (torch.mean(sr * cot_sr.to(dev)) + torch.mean(lq * cot_lq.to(dev))).backward()
+            sd64 = {k: v.double() for k, v in sd32.items()}
+            sr_o, lq_o, ref = realbasicvsr_oracle_grads(sd64, lr.double(), cot_sr.double(), cot_lq.double())
+            assert rel_err(lq, lq_o) < 1e-4 and rel_err(sr, sr_o) < 1e-3
+            grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+            assert set(grads) == set(ref)
+            glob, worst, cos = _grad_report(grads, ref)
+            assert glob < t_glob, (shape, glob, worst)
+            assert worst[0] < t_worst, (shape, worst)
+            cl = {k: v for k, v in ref.items() if k.startswith("cleaner.")}
+            assert len(cl) == 12 and _grad_report(grads, cl)[0] < t_glob
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]
+
+
 _C1 = {}
 
 
@@ -459,7 +498,7 @@ def test_backward_is_linear_in_cotangent_large():
     def bwd(cot):
         gs = [torch.zeros_like(p) if k < n_train else None for k, p in enumerate(ps)]
         assert lib.vsr_basicvsr_backward(ctypes.byref(desc), VF._ptr_array(ps), VF._ptr_array(gs), len(ps), VF._ptr(lrs), VF._ptr(cot),
-                                         VF._ptr(ws), nbytes, st) == 0
+                                         VF._ptr(None), VF._ptr(ws), nbytes, st) == 0
         return torch.cat([g.flatten() for g in gs if g is not None])
 
     c1 = torch.randn_like(sr)
@@ -492,8 +531,6 @@ def test_realbasicvsr_inference_vs_golden(dtype):
     try:
         with torch.no_grad():
             sr, lq = m(lrs)
-        with pytest.raises(NotImplementedError):
-            m(lrs)                                   # grad mode: the pre-clean backward is not on the HIP path
     finally:
         del os.environ["VSRLAB_AMD_DTYPE"]
     assert torch.equal(lrs, keep) and lq.data_ptr() != lrs.data_ptr()

@@ -114,6 +114,33 @@ def test_basicvsr_train_flow_spynet_grads():
     assert full == 9
 
 
+def test_realbasicvsr_training_gradients_vs_reference_under_autocast():
+    """The reference's RealBasicVSR backward only runs under autocast (realbasicvsr.py:29 adds in place; see
+    make_golden.realtrain), so its gradients carry bf16 rounding: the fp64 oracle must agree with them in direction
+    (cosine) and roughly in size -- a LOOSE pin of the pre-clean stack's backward; the forward is pinned sharply by
+    test_realbasicvsr_forward."""
+    from helpers import realbasicvsr_shapes, realbasicvsr_oracle_grads
+    g = golden("realbasicvsr_m64_train_autocast")
+    shape = (1, 3, 3, 24, 40)
+    n, t, _, h, w = shape
+    sd = {k: v.double() for k, v in O.keyed_state_dict(realbasicvsr_shapes(64, 2, 2)).items()}
+    lr = rand(g["seed_lr"], *shape).double()
+    cot_sr = rand(g["seed_cot_sr"], n, t, 3, 4 * h, 4 * w, lo=-1, hi=1).double()
+    cot_lq = rand(g["seed_cot_lq"], n, t, 3, h, w, lo=-1, hi=1).double()
+    sr, lq, grads = realbasicvsr_oracle_grads(sd, lr, cot_sr, cot_lq)
+    assert rel_err(sr, g["sr"]) < 5e-2 and rel_err(lq, g["lq"]) < 5e-2            # bf16 autocast forward
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            name = k[len("grad__"):].replace("__", ".")
+            a, b = grads[name].flatten(), v.double().flatten()
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+            assert cos > 0.97, (name, cos)
+            assert 0.8 < float(a.norm() / b.norm()) < 1.25, name
+            checked += 1
+    assert checked == 7
+
+
 def test_realbasicvsr_forward():
     g = golden("realbasicvsr_m16")
     shapes = {"basicvsr." + k: s for k, s in O.basicvsr_param_shapes(16, 2, 4).items()}

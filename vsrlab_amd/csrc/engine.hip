@@ -874,8 +874,17 @@ int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int
 // ---- RealBasicVSR pre-clean stack, forward (realbasicvsr.py:17-30) ------------------------------------
 // x <- x + conv(ResidualBlock(x)), `steps` times, on the F = n*t frames of the clip.
 // params: resblock.conv.0.{weight,bias}, resblock.res_block.{i}.conv{1,2}.{weight,bias} ..., conv.{weight,bias}
-struct CleanPlan { size_t stem_w, stem_b, out_w, out_b, feat, act, xa, xb, total; std::vector<size_t> blk_w, blk_b; };
-static CleanPlan clean_plan(int F, int h, int w, int blocks, int dtype) {
+struct CleanPlan {
+    size_t stem_w, stem_b, out_w, out_b, feat, act, xa, xb, total;
+    std::vector<size_t> blk_w, blk_b;
+    // need_backward: data-gradient weights, per-step saved tensors, backward scratch
+    bool save = false;
+    size_t stem_wd, out_wd, slab, dXa, dXb, dA, G0, dxa, dxb;
+    std::vector<size_t> blk_wd;
+    std::vector<size_t> xs;             // [steps]: planar fp32 input of each step (xs[0] unused: the caller's lr)
+    std::vector<size_t> X, A;           // [steps][blocks+1] / [steps][blocks]
+};
+static CleanPlan clean_plan(int F, int h, int w, int blocks, int dtype, int steps, bool save) {
     CleanPlan p; Bump b;
     const size_t es = esize(dtype), w64 = (size_t)9 * C * C * es;
     p.stem_w = b.take((size_t)9 * C * 16 * es); p.stem_b = b.take(C * 4);
@@ -883,24 +892,44 @@ static CleanPlan clean_plan(int F, int h, int w, int blocks, int dtype) {
     for (int k = 0; k < 2 * blocks; ++k) { p.blk_w[k] = b.take(w64); p.blk_b[k] = b.take(C * 4); }
     p.out_w = b.take((size_t)9 * 32 * C * es); p.out_b = b.take(64 * 4);
     const size_t a1 = (size_t)F * pm_image_elems(h, w, C) * es;
+    const size_t x1 = (size_t)F * 3 * h * w * 4;
     p.feat = b.take(a1); p.act = b.take(a1);
-    p.xa = b.take((size_t)F * 3 * h * w * 4); p.xb = b.take((size_t)F * 3 * h * w * 4);
+    p.xa = b.take(x1); p.xb = b.take(x1);
+    p.save = save;
+    if (save) {                                   // appended: the forward-only offsets do not move
+        p.stem_wd = b.take((size_t)9 * 32 * C * es); p.out_wd = b.take((size_t)9 * C * 16 * es);
+        p.blk_wd.resize(2 * blocks);
+        for (int k = 0; k < 2 * blocks; ++k) p.blk_wd[k] = b.take(w64);
+        int cp, xp, stride;
+        vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
+        p.slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+        p.dXa = b.take(a1); p.dXb = b.take(a1); p.dA = b.take(a1); p.G0 = b.take(a1);
+        p.dxa = b.take(x1); p.dxb = b.take(x1);
+        p.xs.assign(steps, 0); p.X.assign((size_t)steps * (blocks + 1), 0); p.A.assign((size_t)steps * blocks, 0);
+        for (int s = 0; s < steps; ++s) {
+            if (s > 0) p.xs[s] = b.take(x1);
+            for (int k = 0; k <= blocks; ++k) p.X[(size_t)s * (blocks + 1) + k] = b.take(a1);
+            for (int k = 0; k < blocks; ++k) p.A[(size_t)s * blocks + k] = b.take(a1);
+        }
+    }
     p.total = b.off;
     return p;
 }
 
-size_t vsr_cleaner_workspace_bytes(int F, int h, int w, int blocks, int dtype) {
-    if (F < 1 || h < 1 || w < 1 || blocks < 0) return 0;
-    return clean_plan(F, h, w, blocks, dtype).total;
+size_t vsr_cleaner_workspace_bytes(int F, int h, int w, int blocks, int steps, int dtype, int need_backward) {
+    if (F < 1 || h < 1 || w < 1 || blocks < 0 || steps < 1) return 0;
+    return clean_plan(F, h, w, blocks, dtype, steps, need_backward != 0).total;
 }
 
 int vsr_cleaner_forward(int F, int h, int w, int mid_channels, int blocks, int steps, int dtype, const float* const* params,
-                        int nparams, const float* lr, float* lq, void* workspace, size_t workspace_bytes, void* stream) {
+                        int nparams, const float* lr, float* lq, void* workspace, size_t workspace_bytes, int need_backward,
+                        void* stream) {
     if (F < 1 || h < 1 || w < 1 || blocks < 0 || steps < 1 || !params || !lr || !lq || !workspace) return VSR_ERR_BADARG;
     if (mid_channels != C) return VSR_ERR_UNSUPPORTED;
     if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
     if (nparams != 4 + 4 * blocks) return VSR_ERR_BADARG;
-    const CleanPlan p = clean_plan(F, h, w, blocks, dtype);
+    const bool save = need_backward != 0;
+    const CleanPlan p = clean_plan(F, h, w, blocks, dtype, steps, save);
     if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Plan dummy; dummy.es = esize(dtype);
@@ -910,29 +939,104 @@ int vsr_cleaner_forward(int F, int h, int w, int mid_channels, int blocks, int s
     for (int k = 0; k < 2 * blocks; ++k) {
         CK(c.pack(params[2 + 2 * k], p.blk_w[k], 9, C, C, C, C, C, 0, 1, 0, 0));
         CK(c.pack_bias(params[3 + 2 * k], p.blk_b[k], C));
+        if (save) CK(c.pack(params[2 + 2 * k], p.blk_wd[k], 9, C, C, C, C, C, 0, 1, 0, 1));
     }
     CK(c.pack(params[2 + 4 * blocks], p.out_w, 9, 32, C, 3, C, C, 0, 1, 0, 0));
     CK(c.pack_bias(params[3 + 4 * blocks], p.out_b, 3));
+    if (save) {
+        CK(c.pack(params[0], p.stem_wd, 9, 32, C, 3, C, 3, 0, 1, 0, 1));                  // 64 -> 3 (planar epilogue)
+        CK(c.pack(params[2 + 4 * blocks], p.out_wd, 9, C, 16, C, 3, C, 0, 1, 0, 1));      // 3 (planar source) -> 64
+    }
     const float* xin = lr;
     for (int s = 0; s < steps; ++s) {
-        float* xout = (s == steps - 1) ? lq : (float*)c.at((s & 1) ? p.xb : p.xa);
+        float* xout = (s == steps - 1) ? lq : (float*)c.at(save ? p.xs[s + 1] : ((s & 1) ? p.xb : p.xa));
+        auto Xs = [&](int k) { return save ? c.at(p.X[(size_t)s * (blocks + 1) + k]) : c.at(p.feat); };
         {   // ResidualBlock stem: conv3x3 3->64 + LeakyReLU(0.1) on the planar frames (conv.py:97)
             ConvArgs a = c.base(F, h, w);
             a.src[0] = xin; a.src_nstride[0] = (long long)3 * h * w;
-            a.wpack = c.at(p.stem_w); a.bias = c.fat(p.stem_b); a.dst[0] = c.at(p.feat); a.act = ACT_LEAKY;
+            a.wpack = c.at(p.stem_w); a.bias = c.fat(p.stem_b); a.dst[0] = Xs(0); a.act = ACT_LEAKY;
             CK(vsr_launch_conv(dtype, 3, 1, 16, 16, 1, 64, EPI_NHWC, a, st));
         }
         for (int b = 0; b < blocks; ++b) {
-            CK(c.conv64(c.at(p.feat), p.blk_w[2 * b], c.fat(p.blk_b[2 * b]), c.at(p.act), ACT_RELU, nullptr, nullptr, 0, F, h, w));
-            CK(c.conv64(c.at(p.act), p.blk_w[2 * b + 1], c.fat(p.blk_b[2 * b + 1]), c.at(p.feat), ACT_NONE, c.at(p.feat), nullptr, 0, F, h, w));
+            void* act = save ? c.at(p.A[(size_t)s * blocks + b]) : c.at(p.act);
+            CK(c.conv64(Xs(b), p.blk_w[2 * b], c.fat(p.blk_b[2 * b]), act, ACT_RELU, nullptr, nullptr, 0, F, h, w));
+            CK(c.conv64(act, p.blk_w[2 * b + 1], c.fat(p.blk_b[2 * b + 1]), Xs(b + 1), ACT_NONE, Xs(b), nullptr, 0, F, h, w));
         }
         {   // x + conv3x3 64->3 (realbasicvsr.py:28-29; a fresh tensor instead of the reference's in-place +=)
             ConvArgs a = c.base(F, h, w);
-            a.src[0] = c.at(p.feat); a.wpack = c.at(p.out_w); a.bias = c.fat(p.out_b); a.cout_real = 3;
+            a.src[0] = Xs(blocks); a.wpack = c.at(p.out_w); a.bias = c.fat(p.out_b); a.cout_real = 3;
             a.dst[0] = xout; a.dst_nstride = (long long)3 * h * w; a.pres = xin;
             CK(vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, st));
         }
         xin = xout;
+    }
+    return VSR_OK;
+}
+
+// Backward of the above for the cotangent dlq (F,3,h,w): grads[k] (the 4 + 4*blocks tensors; NULL = not wanted, a bias
+// needs its weight's entry) are ACCUMULATED into; dlr (F,3,h,w, optional) is written.  The parameters are shared by the
+// `steps` iterations, so each iteration adds its weight gradients.
+int vsr_cleaner_backward(int F, int h, int w, int mid_channels, int blocks, int steps, int dtype, float* const* grads, int nparams,
+                         const float* lr, const float* dlq, float* dlr, void* workspace, size_t workspace_bytes, void* stream) {
+    if (F < 1 || h < 1 || w < 1 || blocks < 0 || steps < 1 || !grads || !lr || !dlq || !workspace) return VSR_ERR_BADARG;
+    if (mid_channels != C || blocks < 1) return VSR_ERR_UNSUPPORTED;      // the stem's LeakyReLU mask is fused into block 0's dgrad
+    if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+    if (nparams != 4 + 4 * blocks) return VSR_ERR_BADARG;
+    const CleanPlan p = clean_plan(F, h, w, blocks, dtype, steps, true);
+    if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Plan dummy; dummy.es = esize(dtype); dummy.slab[0] = dummy.slab[1] = p.slab;
+    const Ctx c{dummy, (char*)workspace, st, dtype};
+    const WG wg{c};
+    const float* dx = dlq;                                   // gradient w.r.t. x_{s+1}
+    for (int s = steps - 1; s >= 0; --s) {
+        const float* xs = s == 0 ? lr : c.fat(p.xs[s]);
+        auto Xs = [&](int k) { return c.at(p.X[(size_t)s * (blocks + 1) + k]); };
+        auto As = [&](int k) { return c.at(p.A[(size_t)s * blocks + k]); };
+        float* gow = grads[2 + 4 * blocks]; float* gob = grads[3 + 4 * blocks];
+        {   // out conv 64->3: X = X_blocks, dY = dx (planar)
+            WgradArgs a = wg_base(F, h, w);
+            a.x[0] = Xs(blocks); a.dy[0] = dx; a.dy_nstride = (long long)3 * h * w;
+            CK(wg.run(3, 64, false, 16, true, a, 3, C, gow, C, 0, 1, 0, gob));
+        }
+        size_t dcur = p.dXa, dnext = p.dXb;
+        {   // d X_blocks = dgrad(out conv)(dx)
+            ConvArgs a = c.base(F, h, w);
+            a.src[0] = dx; a.src_nstride[0] = (long long)3 * h * w; a.wpack = c.at(p.out_wd); a.dst[0] = c.at(dcur);
+            CK(vsr_launch_conv(dtype, 3, 1, 16, 16, 1, 64, EPI_NHWC, a, st));
+        }
+        for (int b = blocks - 1; b >= 0; --b) {   // x + conv2(relu(conv1(x)))   (conv.py:89-92)
+            CK(c.conv64(c.at(dcur), p.blk_wd[2 * b + 1], nullptr, c.at(p.dA), ACT_NONE, nullptr, As(b), MASK_RELU, F, h, w));
+            {
+                WgradArgs a = wg_base(F, h, w);
+                a.x[0] = As(b); a.dy[0] = c.at(dcur);
+                CK(wg.run(3, 64, false, 64, false, a, C, C, grads[2 + 2 * (2 * b + 1)], C, 0, 1, 0, grads[3 + 2 * (2 * b + 1)]));
+            }
+            void* out = b > 0 ? c.at(dnext) : c.at(p.G0);      // b == 0: also through the stem's LeakyReLU
+            CK(c.conv64(c.at(p.dA), p.blk_wd[2 * b], nullptr, out, ACT_NONE, c.at(dcur), b == 0 ? Xs(0) : nullptr,
+                        b == 0 ? MASK_LEAKY : 0, F, h, w));
+            {
+                WgradArgs a = wg_base(F, h, w);
+                a.x[0] = Xs(b); a.dy[0] = c.at(p.dA);
+                CK(wg.run(3, 64, false, 64, false, a, C, C, grads[2 + 2 * (2 * b)], C, 0, 1, 0, grads[3 + 2 * (2 * b)]));
+            }
+            const size_t tmp = dcur; dcur = dnext; dnext = tmp;
+        }
+        const void* g0 = c.at(p.G0);
+        {   // stem 3->64: X = x_s (planar), dY = G0
+            WgradArgs a = wg_base(F, h, w);
+            a.x[0] = xs; a.x_nstride = (long long)3 * h * w; a.dy[0] = g0;
+            CK(wg.run(3, 16, true, 64, false, a, C, 3, grads[0], 3, 0, 1, 0, grads[1]));
+        }
+        const bool last = s == 0;
+        if (!last || dlr) {   // d x_s = d x_{s+1} + dgrad(stem)(G0)
+            float* dxs = last ? dlr : (float*)c.at((s & 1) ? p.dxa : p.dxb);
+            ConvArgs a = c.base(F, h, w);
+            a.src[0] = g0; a.wpack = c.at(p.stem_wd); a.cout_real = 3;
+            a.dst[0] = dxs; a.dst_nstride = (long long)3 * h * w; a.pres = dx;
+            CK(vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, st));
+            dx = dxs;
+        }
     }
     return VSR_OK;
 }

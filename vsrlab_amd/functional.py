@@ -392,27 +392,57 @@ def basicvsr_flows(lrs_shape, mid_channels, res_blocks, upscale, ws: Workspace, 
 # --------------------------------------------------------------------------------------------- #
 # RealBasicVSR pre-clean stack, forward (reference: vsr/models/RealBasicVSR/realbasicvsr.py:17-30)
 # --------------------------------------------------------------------------------------------- #
+class _CleanerFn(torch.autograd.Function):
+    """lq = IterativeRefinement(lr) with its backward on the HIP engine (parameter gradients and d lr)."""
+
+    @staticmethod
+    def forward(ctx, lr, meta, *params):
+        mid_channels, blocks, steps, dtype, need_bwd = meta
+        n, t, _, h, w = lr.shape
+        lib = _lib.load()
+        ps = [_f32c(p) for p in params]
+        lr32 = _f32c(lr)
+        nbytes = lib.vsr_cleaner_workspace_bytes(n * t, h, w, blocks, steps, dtype, int(need_bwd))
+        if nbytes == 0:
+            raise RuntimeError("vsrlab_amd: unsupported pre-clean configuration for the HIP path")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=lr.device)
+        lq = torch.empty((n, t, 3, h, w), dtype=torch.float32, device=lr.device)
+        _lib.check(lib.vsr_cleaner_forward(n * t, h, w, mid_channels, blocks, steps, dtype, _ptr_array(ps), len(ps), _ptr(lr32),
+                                           _ptr(lq), _ptr(ws), ws.numel(), int(need_bwd), _stream()), "cleaner_forward")
+        ctx.meta = meta
+        ctx.ws = ws if need_bwd else None
+        ctx.lr32 = lr32 if need_bwd else None
+        ctx.shapes = [p.shape for p in ps]
+        return lq
+
+    @staticmethod
+    def backward(ctx, dlq):
+        mid_channels, blocks, steps, dtype, need_bwd = ctx.meta
+        if not need_bwd:
+            raise RuntimeError("vsrlab_amd: backward through a pre-clean forward that ran without need_backward")
+        n, t, _, h, w = dlq.shape
+        lib = _lib.load()
+        grads = [torch.zeros(sh, dtype=torch.float32, device=dlq.device) for sh in ctx.shapes]
+        dlr = torch.empty_like(ctx.lr32) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.vsr_cleaner_backward(n * t, h, w, mid_channels, blocks, steps, dtype, _ptr_array(grads), len(grads),
+                                            _ptr(ctx.lr32), _ptr(_f32c(dlq)), _ptr(dlr), _ptr(ctx.ws), ctx.ws.numel(), _stream()),
+                   "cleaner_backward")
+        ctx.ws = None
+        return (dlr, None) + tuple(g if ctx.needs_input_grad[2 + k] else None for k, g in enumerate(grads))
+
+
 def cleaner_forward(params: Sequence[torch.Tensor], lr: torch.Tensor, mid_channels: int, blocks: int, steps: int = 3,
                     compute_dtype: Optional[str] = None) -> torch.Tensor:
-    """lq = IterativeRefinement(lr): (n,t,3,h,w) -> (n,t,3,h,w), a fresh tensor.  Inference only for now."""
+    """lq = IterativeRefinement(lr): (n,t,3,h,w) -> (n,t,3,h,w), a fresh tensor (the reference adds in place,
+    realbasicvsr.py:29).  Differentiable w.r.t. the parameters and lr."""
     _require_gpu(lr)
-    if torch.is_grad_enabled() and (lr.requires_grad or any(p.requires_grad for p in params)):
-        raise NotImplementedError("the backward of the RealBasicVSR pre-clean stack is not on the HIP path yet "
-                                  "(it needs the SPyNet input gradient); run it under torch.no_grad()")
     if len(params) != 4 + 4 * blocks:
         raise ValueError("expected the 4 + 4*blocks tensors of IterativeRefinement")
     n, t, c, h, w = lr.shape
     if c != 3:
         raise ValueError("lr must be (n,t,3,h,w)")
-    dtype = resolve_dtype(compute_dtype)
-    lib = _lib.load()
-    ps = [_f32c(p) for p in params]
-    nbytes = lib.vsr_cleaner_workspace_bytes(n * t, h, w, blocks, dtype)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=lr.device)
-    lq = torch.empty((n, t, 3, h, w), dtype=torch.float32, device=lr.device)
-    _lib.check(lib.vsr_cleaner_forward(n * t, h, w, mid_channels, blocks, steps, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(lr)),
-                                       _ptr(lq), _ptr(ws), ws.numel(), _stream()), "cleaner_forward")
-    return lq
+    need_bwd = torch.is_grad_enabled() and (lr.requires_grad or any(p.requires_grad for p in params))
+    return _CleanerFn.apply(lr, (mid_channels, blocks, steps, resolve_dtype(compute_dtype), need_bwd), *params)
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -1,12 +1,12 @@
 """``RealBasicVSR`` plugin surface (vsrlab ``src/vsr/models/RealBasicVSR/realbasicvsr.py:5-30``,
 the ``_target_`` of conf/train/model/basicvsr.yaml).  ``sr, lq = model(lr)``.
 
-Both stages run on the HIP engine for inference (``torch.no_grad()``): the pre-clean stack reuses the
-trunk kernels (3->64 stem on the planar frames, 64->64 residual blocks, 64->3 conv with the ``x +``
-fused as a planar residual).  Training through the pre-clean stack needs the gradient w.r.t. the LR
-clip, incl. the path through SPyNet's inputs: that raises instead of silently
-falling back.  ``lq`` is a fresh tensor; the reference mutates ``lr`` in place and returns it
-(realbasicvsr.py:26-30) -- the values are identical."""
+Both stages run on the HIP engine, forward and backward: the pre-clean stack reuses the trunk kernels (3->64
+stem on the planar frames, 64->64 residual blocks, 64->3 conv with the ``x +`` fused as a planar residual) and
+its backward receives the gradient w.r.t. ``lq`` from BasicVSR (bilinear x4 skip, the stems' LR channels, the
+flows through SPyNet's image pyramid).  ``lq`` is a fresh tensor; the reference mutates ``lr`` in place and
+returns it (realbasicvsr.py:26-30) -- the values are identical, and the reference's own
+backward only runs under autocast because of it."""
 import torch.nn as nn
 
 from .... import functional as VF
