@@ -597,13 +597,15 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
     return VSR_OK;
 }
 
-int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g) {
+int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g, const float* last2_w) {
     const PIdx ix{p.rb};
     const WG wg{c};
     const int n = p.n, h = p.h, w = p.w, H4 = 4 * h, W4 = 4 * w;
     const float* dsr_i = dsr + (size_t)i * 3 * H4 * W4;
     const long long dsr_ns = (long long)p.t * 3 * H4 * W4;
-    {   // d(conv_last.0 pre-activation) = dgrad(conv_last.2)(dsr) * LeakyReLU'(C0)
+    if (c.dtype == VSR_BF16 && last2_w) {   // d(conv_last.0 pre-activation) = dgrad(conv_last.2)(dsr) * LeakyReLU'(C0): hr_tail.hip
+        CK(vsr_launch_last2_dgrad(dsr_i, dsr_ns, last2_w, c.at(p.C0[i]), c.at(p.G_C0), n, H4, W4, MASK_LEAKY, c.st));
+    } else {
         ConvArgs a = c.base(n, H4, W4);
         a.src[0] = dsr_i; a.src_nstride[0] = dsr_ns; a.wpack = c.at(p.last2_wd); a.dst[0] = c.at(p.G_C0);
         a.aux[0] = c.at(p.C0[i]); a.mask_mode = MASK_LEAKY;
@@ -732,7 +734,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     const Ctx c{p, ws, st, p.dtype, 0};
     // input gradient, part 1: the bilinear x4 skip (basicvsr.py:22,82) -- overwrites dlrs, everything else accumulates
     if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st));
-    for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g));   // -> dFeatB[i], dFF[i]
+    for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
     CK(f.begin());
     const Ctx c1{p, ws, f.side(), p.dtype, 1};
