@@ -376,6 +376,7 @@ int launch_inst(const ConvArgs& a, hipStream_t st) {
     X(7, 1, 16, 16, false, 32, EPI_PLANAR)  /* SPyNet 16->2 (+ReLU) + flow_up residual          */
 
 int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st);
+int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);      // hr_tail.hip
 
 // VSRLAB_AMD_GENERIC_CONV=1 routes the hot shape through the generic tiled kernel (A/B testing only).
 static bool vsr_force_generic_conv() {
@@ -406,6 +407,12 @@ int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar
             num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         const int ps = vsr_launch_conv3x3_c64_persist(a, num_cus, st);
+        if (ps != VSR_ERR_UNSUPPORTED) return ps;
+    }
+    // 64 -> (<= 4) channels with a planar destination: streaming kernel of hr_tail.hip
+    if (dtype == VSR_BF16 && ks == 3 && nsrc == 1 && ca == 64 && cb == 64 && !last_planar && cout_t == 32 && epi == EPI_PLANAR &&
+        !vsr_force_generic_conv()) {
+        const int ps = vsr_launch_c64_to_planar(a, st);
         if (ps != VSR_ERR_UNSUPPORTED) return ps;
     }
 #define X(KS, NSRC, CA, CB, LP, COUT, EPI)                                                             \

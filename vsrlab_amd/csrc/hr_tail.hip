@@ -111,6 +111,154 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
     }
 }
 
+// PyTorch upsample_bilinear2d(align_corners=False) source index for scale 1/4 (basicvsr.py:22)
+__device__ __forceinline__ void hr_bil4(int d, int in_size, int& i0, int& i1, float& l1) {
+    float s = (d + 0.5f) * 0.25f - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+// conv3x3 64 -> (<= 4) channels with a planar fp32 destination: conv_last.2 + bilinear x4 skip (basicvsr.py:21-22,82),
+// the pre-clean stack's `x + conv` (realbasicvsr.py:28-29), the stems' LR-channel data gradient.  M = 16 rows (<= 4
+// real) x N = 16 pixels x K = 32 channels per v_mfma_f32_16x16x32_bf16: all 18 (tap, channel-half) weight fragments live
+// in registers; the haloed 10 x 34 pixel tile is staged in LDS in the image the persistent kernel uses
+// ([row][8 chunks][34 px][16 B]: a B fragment is one ds_read_b128, 16 lanes = 16 consecutive slots).  The kernel streams:
+// 43.5 KB in, <= 4 KB out per tile; three workgroups per CU cover each other's staging latency.
+constexpr int FP_CH = LT_RS * 16, FP_ROW = 8 * FP_CH, FP_TILE = (LT_H + 2) * FP_ROW;      // 544 / 4352 / 43,520 bytes
+constexpr int FP_CHUNKS = FP_TILE / 16;                                                   // 2,720 16-byte slots
+constexpr int FP_NPIECE = (FP_CHUNKS + 63) / 64, FP_NPIECE_W = (FP_NPIECE + 3) / 4;      // 43 DMA pieces, 11 per wave
+constexpr int FP_NT = 512;
+__device__ uint4 g_fp_zero_chunk[2];
+
+#define FP_GLDS16(src, dst)                                                                           \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// Same structure as conv3x3_c64_persist_kernel with ONE 16-row cout block: a persistent 512-thread workgroup per CU,
+// 4 producer waves filling the other tile buffer by LDS-DMA a tile ahead, 4 MFMA waves (tile rows 2w, 2w+1).
+__global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char tiles[];      // 2 x FP_TILE
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
+    const int i15 = lane & 15, q = lane >> 4;
+    const int ntx = cdiv(a.W, LT_W), nty = cdiv(a.H, LT_H);
+    const int total = a.N * ntx * nty;
+    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
+
+    if (role == 1) {
+        const char* src = reinterpret_cast<const char*>(a.src[0]);
+        const char* zsrc = reinterpret_cast<const char*>(g_fp_zero_chunk);
+        const int WSs = pm_ws(a.Ws);
+        int rel[FP_NPIECE_W];
+#pragma unroll
+        for (int i = 0; i < FP_NPIECE_W; ++i) {
+            const int idx = (w4 + 4 * i) * 64 + lane;           // LDS slot = [row ty][chunk c][34 pixels tx] x 16 B
+            const int ty = idx / (8 * LT_RS), rem = idx - ty * (8 * LT_RS);
+            const int c = rem / LT_RS, dx = rem - c * LT_RS - 1;
+            rel[i] = ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+        }
+        auto issue = [&](int tile, int buf) {
+            const int n = tile / (ntx * nty), r = tile - n * (ntx * nty);
+            const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+            const char* org = src + ((long long)n * a.src_nstride[0] + pm_off(ty0, tx0, 0, a.Ws, 64)) * 2;
+            char* dstb = tiles + buf * FP_TILE;
+            const bool interior = ty0 >= 1 && ty0 + LT_H < a.H && tx0 >= 1 && tx0 + LT_W < a.W;
+#pragma unroll
+            for (int i = 0; i < FP_NPIECE_W; ++i) {
+                const int piece = w4 + 4 * i;
+                const int idx = piece * 64 + lane;
+                const char* s = org + rel[i];
+                if (!interior) {
+                    const int ty = idx / (8 * LT_RS), tx = (idx - ty * (8 * LT_RS)) % LT_RS;
+                    const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+                    if (!(vy >= 0 && vy < a.H && vx >= 0 && vx < a.W)) s = zsrc;
+                }
+                if (piece < FP_NPIECE && idx < FP_CHUNKS) FP_GLDS16(s, dstb + piece * 1024);
+            }
+        };
+        int cur = 0, tile = walk.first;
+        if (tile < walk.end) issue(tile, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (; tile < walk.end; tile += walk.stride) {
+            const int next = tile + walk.stride;
+            if (next < walk.end) issue(next, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+        return;
+    }
+
+    // A[m = cout i][k = 8 q + j] of every (tap, channel half) from the packed weights [9][32 rows][64] bf16: in registers
+    bf16x8_t fa[9][2];
+    {
+        const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.wpack);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fa[tap][kk] = *reinterpret_cast<const bf16x8_t*>(wp + ((tap * 32 + i15) * 64 + kk * 32 + 8 * q));
+    }
+    const long long plane = (long long)a.Hd * a.Wd;
+    __syncthreads();                                         // the first tile is in LDS
+    int cur = 0;
+    for (int t = walk.first; t < walk.end; t += walk.stride) {
+        const int n = t / (ntx * nty), r = t - n * (ntx * nty);
+        const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+        // epilogue operands first (their latency hides behind the MFMAs).  The accumulator rows that matter (m = 0..3)
+        // sit in lanes 0-15 only; after the K loop they are broadcast so that lane group q finishes pixel block nb = q:
+        // all 64 lanes load / store, one pixel each.
+        const int oy = ty0 + 2 * w4 + (q >> 1), ox = tx0 + (q & 1) * 16 + i15;
+        const bool ok = oy < a.H && ox < a.W;
+        float add[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            int y0 = 0, y1 = 0, x0 = 0, x1 = 0; float ly = 0.f, lx = 0.f;
+            if (a.base_lr) { hr_bil4(oy, a.base_h, y0, y1, ly); hr_bil4(ox, a.base_w, x0, x1, lx); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= a.cout_real) break;
+                float v = a.bias ? a.bias[c] : 0.f;
+                if (a.pres) v += a.pres[(long long)n * a.dst_nstride + c * plane + (long long)oy * a.Wd + ox];
+                if (a.base_lr) {
+                    const float* bp = a.base_lr + (long long)n * a.base_nstride + (long long)c * a.base_h * a.base_w;
+                    const float v00 = bp[y0 * a.base_w + x0], v01 = bp[y0 * a.base_w + x1];
+                    const float v10 = bp[y1 * a.base_w + x0], v11 = bp[y1 * a.base_w + x1];
+                    v += (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                }
+                add[c] = v;
+            }
+        }
+        f32x4_t acc[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const char* tb = tiles + cur * FP_TILE + (2 * w4) * FP_ROW + q * FP_CH + i15 * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(tb + ((nb >> 1) + tap / 3) * FP_ROW + kk * 4 * FP_CH +
+                                                                            ((nb & 1) * 16 + tap % 3) * 16);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tap][kk], fb, acc[nb], 0, 0, 0);
+                }
+        float* dst = reinterpret_cast<float*>(a.dst[0]) + (long long)n * a.dst_nstride + (long long)oy * a.Wd + ox;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= a.cout_real) break;
+            const float s0 = __shfl(acc[0][c], i15, 64), s1 = __shfl(acc[1][c], i15, 64);
+            const float s2 = __shfl(acc[2][c], i15, 64), s3 = __shfl(acc[3][c], i15, 64);
+            const float v = (q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : s3) + add[c];
+            if (ok) dst[c * plane] = v;
+        }
+        __syncthreads();                                     // the producers' next tile has landed; this one is consumed
+        cur ^= 1;
+    }
+}
+
 }  // namespace
 
 // dX (pixel-major bf16, 64 channels) = mask(aux) * dgrad of a 64 -> 3 3x3 conv, from the planar fp32 cotangent dsr
@@ -122,6 +270,31 @@ int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float*
     const int grid = tiles < 256 * 8 ? tiles : 256 * 8;
     hipLaunchKernelGGL(last2_dgrad_kernel, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (bf16_t*)dst, N, H, W,
                        mask_mode);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+// bf16 conv3x3 64 -> cout_real <= 4 channels, planar fp32 destination (+ bias, + planar residual, + bilinear x4 skip);
+// returns VSR_ERR_UNSUPPORTED for anything else (the caller then uses the generic kernel).
+int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st) {
+    if (a.nz != 1 || a.act != ACT_NONE || a.cout_real < 1 || a.cout_real > 4 || a.in_step != 1 || a.src_oy[0] != 0 || a.src_ox[0] != 0 ||
+        a.Hs != a.H || a.Ws != a.W || a.out_step != 1 || a.Hd != a.H || a.Wd != a.W || !a.src[0] || a.aux[0] || a.res[0])
+        return VSR_ERR_UNSUPPORTED;
+    if (pm_image_elems(LT_H + 4, a.Ws, 64) * 2 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;     // in-tile source offsets are 32-bit
+    static bool attr_set = false;
+    static int num_cus = 0;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(c64_to_planar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FP_TILE));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HIP_CHECK_RET(hipGetDevice(&dev));
+        HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_set = true;
+    }
+    const int tiles = a.N * cdiv(a.W, LT_W) * cdiv(a.H, LT_H);
+    const int grid = tiles < num_cus ? tiles : num_cus;
+    hipLaunchKernelGGL(c64_to_planar_kernel, dim3(grid), dim3(FP_NT), 2 * FP_TILE, st, a);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
