@@ -518,6 +518,11 @@ struct WG {   // one weight-gradient launch + reduction
         if (nwg > cap) nwg = (int)cap;
         if (nwg > 1) nwg &= ~1;
         int nslabs = 0;
+        if (c.dtype == VSR_BF16 && ks == 3 && cx == 64 && !xp && cout == 16 && dyp && a.nseg == 1 && a.x_step == 1 && a.dy_step == 1 &&
+            a.Hx == a.H && a.Wx == a.W && a.Hy == a.H && a.Wy == a.W) {
+            // 64 -> 3 conv with a planar cotangent (conv_last.2, the pre-clean out conv): streaming kernel of hr_tail.hip
+            CK(vsr_launch_last2_wgrad(a.x[0], reinterpret_cast<const float*>(a.dy[0]), a.dy_nstride, a.slab, stride, a.N, a.H, a.W, &nslabs, c.st));
+        } else
         CK(vsr_launch_wgrad(c.dtype, ks, cx, xp, cout, dyp, a, nwg, &nslabs, c.st));
         if (!gw) return VSR_ERR_BADARG;
         return vsr_launch_wgrad_reduce(a.slab, nslabs, ks, cx, cout, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, 1, c.st);

@@ -33,6 +33,8 @@ int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int
 int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu, int h, int w, hipStream_t st);
 int vsr_launch_add_f32(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);
+int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride, float* slab, int slab_stride, int N, int H, int W,
+                           int* nslabs, hipStream_t st);
 int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float* w, const void* aux, void* dst, int N, int H, int W,
                            int mask_mode, hipStream_t st);
 int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
