@@ -33,7 +33,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define VSR_MAX_Z 4
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
-enum { MASK_NONE = 0, MASK_RELU = 1, MASK_LEAKY = 2 };
+enum { MASK_NONE = 0, MASK_RELU = 1, MASK_LEAKY = 2, MASK_RELU_BITS = 3 };   // _BITS: internal to the persistent kernel
 enum { EPI_NHWC = 0, EPI_PLANAR = 1 };
 
 // One implicit-GEMM convolution launch (stride 1, "same" zero padding, KS x KS).
@@ -68,6 +68,12 @@ struct ConvArgs {
     const float* base_lr;
     long long base_nstride;
     int base_h, base_w;
+    // Sign bits of a ReLU output, 1 bit per element, in the persistent kernel's own tile order ([tile][wave][lane] x
+    // 8 bytes): written by the bias+ReLU launch (sign_out), read by the masked data-gradient launch of the same
+    // tensor shape (sign_bits) INSTEAD of re-reading the bf16 activation `aux` (66 MB -> 4 MB at 540p).  Other kernels
+    // ignore both and use `aux`.
+    void* sign_out[VSR_MAX_Z];
+    const void* sign_bits[VSR_MAX_Z];
 };
 
 // Weight-gradient launch: dW[z][tap][cout][cin] = sum_p dY[p][cout] * X[p + tap][cin] over up to

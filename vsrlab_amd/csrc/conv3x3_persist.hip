@@ -217,7 +217,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oy[z], tx0 * a.out_step, 0, a.Wd, 64);
             bool ok[4];
             constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE;   // both operands early would not fit 2 waves / SIMD
+            constexpr bool BITS = MASK == MASK_RELU_BITS;
             bf4 rr[4][4], mm[4][4];                                  // [mb][nb]
+            uint2 sbits = make_uint2(0u, 0u);                         // 64 sign bits of this lane's 64 outputs of the tile
+            if (BITS) sbits = reinterpret_cast<const uint2*>(a.sign_bits[z])[(long long)tile * 256 + w4 * 64 + lane];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 ok[nb] = (tx0 + (nb & 1) * 16 + l15 < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     for (int mb = 0; mb < 4; ++mb) {
                         const long long o = tbase + loff[nb] + mb * 512;
                         if (HAS_RES) rr[mb][nb] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + o);
-                        if (MASK != MASK_NONE && !LATE_MASK) mm[mb][nb] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
+                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[mb][nb] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
                     }
                 }
             }
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             STAMP(t2);
 
             // ---- epilogue, entirely in registers; a store covers two 256-byte runs (two chunks x 16 pixels) per wave ----
+            unsigned sout[2] = {0u, 0u};                             // sign bits written by the bias+ReLU variant: bit (4 mb + nb) * 4 + j
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 if (ok[nb]) {
@@ -308,7 +312,16 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += (float)rr[mb][nb].v[j];
                         }
-                        if (MASK != MASK_NONE) {
+                        if (ACT == ACT_RELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) sout[(mb * 4 + nb) >> 3] |= (v[j] > 0.f ? 1u : 0u) << ((((mb * 4 + nb) & 7) * 4) + j);
+                        }
+                        if (BITS) {
+                            const unsigned wbits = ((mb * 4 + nb) >> 3) ? sbits.y : sbits.x;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)     // sign-extended 1-bit field = all-ones / zero mask on the float's bits
+                                v[j] = __uint_as_float(__float_as_uint(v[j]) & (unsigned)__builtin_amdgcn_sbfe((int)wbits, (((mb * 4 + nb) & 7) * 4) + j, 1));
+                        } else if (MASK != MASK_NONE) {
                             constexpr float neg = MASK == MASK_LEAKY ? 0.1f : 0.f;
                             const bf4 mv = LATE_MASK ? *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[nb] + mb * 512)
                                                      : mm[mb][nb];
@@ -322,6 +335,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     }
                 }
             }
+            if (ACT == ACT_RELU && a.sign_out[z])
+                reinterpret_cast<uint2*>(a.sign_out[z])[(long long)tile * 256 + w4 * 64 + lane] = make_uint2(sout[0], sout[1]);
             STAMP(t3);
             __syncthreads();                               // the producers' next tile has landed; everybody has finished reading `cur`
             cur ^= 1;
@@ -368,7 +383,12 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     bool res = false, aux = false;
     for (int z = 0; z < a.nz; ++z) { res = res || a.res[z]; aux = aux || a.aux[z]; }
     for (int z = 0; z < a.nz; ++z) if ((res && !a.res[z]) || (aux && !a.aux[z])) return VSR_ERR_UNSUPPORTED;
-    const int mask = aux ? a.mask_mode : MASK_NONE;
+    int mask = aux ? a.mask_mode : MASK_NONE;
+    if (mask == MASK_RELU && !res) {                       // sign bits instead of the activation, if every z has them
+        bool bits = true;
+        for (int z = 0; z < a.nz; ++z) bits = bits && a.sign_bits[z];
+        if (bits) mask = MASK_RELU_BITS;
+    }
     if (pm_image_elems((PTHH + 2) * a.in_step, a.Ws, 64) * 2 > 0x7fffffffLL || pm_image_elems(2 * PTH + 2, a.Wd, 64) > 0x7fffffffLL)
         return VSR_ERR_UNSUPPORTED;                                                  // in-tile offsets are 32-bit
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
@@ -377,6 +397,7 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     PERSIST_CASE(ACT_LEAKY, false, MASK_NONE)    // conv_last.0
     PERSIST_CASE(ACT_NONE, false, MASK_NONE)     // upsample phases, plain dgrads
     PERSIST_CASE(ACT_NONE, false, MASK_RELU)     // dgrad(conv2) * ReLU'
+    PERSIST_CASE(ACT_NONE, false, MASK_RELU_BITS)   // the same, from the sign bits the bias+ReLU launch left (4 MB instead of 66 MB)
     PERSIST_CASE(ACT_NONE, true, MASK_LEAKY)     // (dgrad(conv1 of block 0) + dX) * LeakyReLU' of the stem
 #undef PERSIST_CASE
     return VSR_ERR_UNSUPPORTED;

@@ -100,6 +100,7 @@ struct Plan {
     size_t flows;               // fp32 planar [2*n*(t-1)][2][h][w]: first half backward, second half forward
     // trunk activations: [dir][frame]
     std::vector<size_t> Wp[2], X[2], A[2];      // X: (rb+1) per frame, A: rb per frame (saved mode)
+    std::vector<size_t> SB[2];                  // sign bits of A (bf16 build): rb per frame, 8 bytes per lane and 8x32 tile
     std::vector<size_t> feat[2];                // = X[rb]
     size_t scratchA[2], scratchW[2];            // inference mode, per direction (the directions run concurrently)
     // reconstruction
@@ -115,6 +116,7 @@ struct Plan {
 
     size_t xoff(int dir, int i, int b) const { return X[dir][(size_t)i * (rb + 1) + b]; }
     size_t aoff(int dir, int i, int b) const { return A[dir][(size_t)i * rb + b]; }
+    size_t sboff(int dir, int i, int b) const { return SB[dir][(size_t)i * rb + b]; }
     size_t g1off(int dir, int i, int b) const { return G1[dir][(size_t)i * rb + b]; }
     size_t dxoff(int dir, int i, int b) const { return DX[dir][(size_t)i * (rb + 1) + b]; }
 
@@ -146,11 +148,13 @@ struct Plan {
         for (int dir = 0; dir < 2; ++dir) {
             Wp[dir].assign(t, 0); feat[dir].assign(t, 0);
             if (bwd) {
-                X[dir].assign((size_t)t * (rb + 1), 0); A[dir].assign((size_t)t * rb, 0);
+                X[dir].assign((size_t)t * (rb + 1), 0); A[dir].assign((size_t)t * rb, 0); SB[dir].assign((size_t)t * rb, 0);
+                const size_t sbytes = dtype == VSR_BF16 ? (size_t)n * cdiv(h, 8) * cdiv(w, 32) * 2048 : 256;
                 for (int i = 0; i < t; ++i) {
                     Wp[dir][i] = b.take(a1);
                     for (int k = 0; k <= rb; ++k) X[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
                     for (int k = 0; k < rb; ++k) A[dir][(size_t)i * rb + k] = b.take(a1);
+                    for (int k = 0; k < rb; ++k) SB[dir][(size_t)i * rb + k] = b.take(sbytes);
                     feat[dir][i] = xoff(dir, i, rb);
                 }
             } else {
@@ -213,9 +217,10 @@ struct Ctx {
     }
     // y = act(conv3x3(x) + bias) (+res) (*mask(aux)) -- 64 -> 64 at one resolution
     int conv64(const void* x, size_t wpack, const float* bias, void* y, int act, const void* res, const void* aux, int mask,
-               int N, int H, int W) const {
+               int N, int H, int W, void* sign_out = nullptr, const void* sign_bits = nullptr) const {
         ConvArgs a = base(N, H, W);
         a.src[0] = x; a.wpack = at(wpack); a.bias = bias; a.dst[0] = y; a.act = act; a.res[0] = res; a.aux[0] = aux; a.mask_mode = mask;
+        a.sign_out[0] = sign_out; a.sign_bits[0] = sign_bits;
         return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
     }
     // conv3x3 64->256 + PixelShuffle(2): x (N,H,W,64) -> y (N,2H,2W,64)   (upsampling.py:10-12)
@@ -389,7 +394,8 @@ int trunk_forward(const Ctx& c, const Plan& p, int dir, int i, const void* warpe
     for (int b = 0; b < rb; ++b) {      // x + conv2(relu(conv1(x)))   (conv.py:89-92)
         void* act = p.bwd ? c.at(p.aoff(dir, i, b)) : c.at(p.scratchA[dir]);
         void* xn = p.bwd ? c.at(p.xoff(dir, i, b + 1)) : x;   // inference: in place (residual read = own pixel)
-        CK(c.conv64(x, p.blk_w[dir][2 * b], c.fat(p.blk_b[dir][2 * b]), act, ACT_RELU, nullptr, nullptr, 0, n, h, w));
+        CK(c.conv64(x, p.blk_w[dir][2 * b], c.fat(p.blk_b[dir][2 * b]), act, ACT_RELU, nullptr, nullptr, 0, n, h, w,
+                    (p.bwd && c.dtype == VSR_BF16) ? c.at(p.sboff(dir, i, b)) : nullptr));
         CK(c.conv64(act, p.blk_w[dir][2 * b + 1], c.fat(p.blk_b[dir][2 * b + 1]), xn, ACT_NONE, x, nullptr, 0, n, h, w));
         x = xn;
     }
@@ -664,7 +670,8 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
     for (int b = rb - 1; b >= 0; --b) {
         const void* dxn = c.at(p.dxoff(dir, i, b + 1));
         // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
-        CK(c.conv64(dxn, p.blk_wd[dir][2 * b + 1], nullptr, c.at(p.g1off(dir, i, b)), ACT_NONE, nullptr, c.at(p.aoff(dir, i, b)), MASK_RELU, n, h, w));
+        CK(c.conv64(dxn, p.blk_wd[dir][2 * b + 1], nullptr, c.at(p.g1off(dir, i, b)), ACT_NONE, nullptr, c.at(p.aoff(dir, i, b)), MASK_RELU, n, h, w,
+                    nullptr, c.dtype == VSR_BF16 ? c.at(p.sboff(dir, i, b)) : nullptr));
         // dX_b = dX_{b+1} + dgrad(conv1)(dA); for b == 0 also through the stem's LeakyReLU
         void* out = b > 0 ? c.at(p.dxoff(dir, i, b)) : c.at(p.G0[dir][i]);
         CK(c.conv64(c.at(p.g1off(dir, i, b)), p.blk_wd[dir][2 * b], nullptr, out, ACT_NONE, dxn, b == 0 ? c.at(p.xoff(dir, i, 0)) : nullptr,
