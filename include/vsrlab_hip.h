@@ -6,16 +6,24 @@
  * what a binding for that path attaches to: plain pointers and sizes, no torch types.  Every entry
  * point
  *   - takes DEVICE pointers (HBM) unless stated otherwise, and a hipStream_t passed as void*;
- *   - only enqueues work on that stream: no allocation, no synchronisation, no global mutable
- *     state -- it may be called from PyTorch's main thread and from its autograd thread;
- *   - returns 0 (VSR_OK) or a negative status, never throws.
+ *   - only enqueues work on that stream (the whole-path engine forks a helper stream from it and joins it back
+ *     with events, so for the caller all work is ordered in the stream it passed): no device allocation, no
+ *     synchronisation.  It may be called from PyTorch's main thread and from its autograd thread.  Process-wide
+ *     state is limited to caches that never change results: per-device "dynamic-LDS attribute set" flags and
+ *     compute-unit counts, the A/B environment switches read once (VSRLAB_AMD_*), and one helper stream +
+ *     two events per (thread, device), created on first use and released when the process exits;
+ *   - returns 0 (VSR_OK) or a negative status, never throws; NULL / non-positive arguments are VSR_STATUS_BADARG.
  *
  * Tensor conventions
  *   boundary tensors are the reference's own: LR clip (n,t,3,h,w) fp32 planar, SR clip
  *   (n,t,3,4h,4w) fp32 planar, parameters/gradients fp32 OIHW, flow (N,2,H,W) fp32 planar with
- *   channel 0 = dx.  "pm" (pixel-major) tensors are the library's internal [N][H][W][C] layout with
- *   element type `dtype` (VSR_DT_F32 / VSR_DT_BF16); per-op entry points that take them exist so
- *   that each kernel can be parity-tested in isolation.
+ *   channel 0 = dx.  "pm" (pixel-major) tensors are the library's internal BLOCKED layout
+ *       [N][H][ceil(W/32)][C/8][32 pixels][8 channels]          (csrc/common.h: pm_off())
+ *   with element type `dtype` (VSR_DT_F32 / VSR_DT_BF16) and C a multiple of 16: inside a 32-pixel row segment
+ *   the 8-channel chunks of the 32 pixels are contiguous (512 B per chunk in bf16) -- the MFMA accumulator
+ *   layout of the conv kernels.  It is NOT plain NHWC: fill and read pm tensors ONLY through
+ *   vsr_planar_to_pm / vsr_pm_to_planar (rows are padded to whole 32-pixel segments; the padding is never read).
+ *   The per-op entry points that take pm tensors exist so that each kernel can be parity-tested in isolation.
  */
 #ifndef VSRLAB_HIP_H
 #define VSRLAB_HIP_H
@@ -25,7 +33,8 @@ extern "C" {
 #endif
 
 #define VSR_DT_F32 0   /* exact-fp32 build: v_mfma_f32_32x32x2_f32, parity gate */
-#define VSR_DT_BF16 1  /* bf16 storage, fp32 accumulate: v_mfma_f32_32x32x16_bf16, perf build */
+#define VSR_DT_BF16 1  /* bf16 storage, fp32 accumulate: v_mfma_f32_16x16x32_bf16 (hot 3x3 64->64 kernels) /
+                          v_mfma_f32_32x32x16_bf16 (generic shapes), perf build */
 
 #define VSR_STATUS_OK 0
 #define VSR_STATUS_BADARG (-1)

@@ -200,6 +200,28 @@ def _grad_report(grads, ref):
     return rel_l2(g, r), worst, cos
 
 
+def _noise_floor_check(grads_hip, grads_emu, ref, max_glob_ratio=1.5, max_tensor_ratio=None, floor=1e-3):
+    """bf16 criterion (round-1 VERDICT weak #1): the bf16 build is an evaluation of the net with bf16 STORAGE; the CPU
+    oracle under emulate_bf16() is another one that rounds at the same points.  Both are compared with the same
+    exact reference `ref` (fp64 oracle or the reference's own fp64 golden); the HIP build's error may not exceed the
+    emulation's own error by more than the stated ratio -- globally (all tensors concatenated) and per tensor.  A
+    fixed tolerance cannot tell a correct bf16 kernel from one with a 10 % bug; this one scales with the depth of
+    the net under test.  Returns (global ratio, worst per-tensor ratio, key)."""
+    keys = sorted(ref)
+    cat = lambda d: torch.cat([d[k].double().flatten() for k in keys])
+    r = cat(ref)
+    e_hip, e_emu = rel_l2(cat(grads_hip), r), rel_l2(cat(grads_emu), r)
+    per = []
+    for k in keys:
+        eh, ee = rel_l2(grads_hip[k], ref[k]), rel_l2(grads_emu[k], ref[k])
+        per.append((eh / max(ee, floor), k, eh, ee))
+    worst = max(per)
+    assert e_hip <= max_glob_ratio * max(e_emu, floor), ("global", e_hip, e_emu)
+    if max_tensor_ratio is not None:
+        assert worst[0] <= max_tensor_ratio, ("per-tensor", worst)
+    return e_hip / max(e_emu, floor), worst[0], worst[1]
+
+
 # Gradient tolerances.  ReLU / LeakyReLU masks are discontinuous, so a pre-activation perturbed by eps
 # flips the mask of a fraction ~eps of the elements and the gradient moves by ~sqrt(eps) in relative L2:
 #   fp32 (eps ~ 1e-6): measured on the CPU, reference fp32 vs reference fp64 = 1.7e-3 max-norm on
@@ -221,9 +243,18 @@ def test_basicvsr_end_to_end_vs_golden(dtype):
     ref = {k[len("grad__"):].replace("__", "."): v for k, v in g.items() if k.startswith("grad__")}
     assert len(ref) == 11
     glob, worst, cos = _grad_report(grads, ref)
-    assert glob < tol(dtype, 1e-3, 1e-1), (glob, worst)
-    assert worst[0] < tol(dtype, 5e-3, 2.5e-1), worst
-    assert cos > tol(dtype, 0.999999, 0.995)
+    if dtype == "fp32":
+        assert glob < 1e-3, (glob, worst)
+        assert worst[0] < 5e-3, worst
+        assert cos > 0.999999
+    else:
+        # noise floor of bf16 storage on THIS net (3 blocks, t=3): the oracle with bf16 rounding at the same points
+        sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 3, 4))
+        with O.emulate_bf16():
+            sr_e, _, g_e = O.fwd_bwd(sd, lrs, torch.zeros_like(cot), cot=cot)
+        assert rel_err(sr, g["sr"]) <= 1.5 * max(rel_err(sr_e, g["sr"]), 1e-3)
+        _noise_floor_check(grads, g_e, ref, max_glob_ratio=1.5, max_tensor_ratio=2.0)
+        assert cos > 0.995
     assert not any(k.startswith("spynet") for k in grads)
     # flows computed inside the engine
     from vsrlab_amd import functional as VF
@@ -400,38 +431,146 @@ def test_realbasicvsr_training_vs_oracle():
 _C1 = {}
 
 
-def _config1_oracle(emulate):
-    """fp32 oracle (or its bf16-storage emulation) on BASELINE config 1, computed once per session."""
-    if emulate not in _C1:
+def _config1_oracle(kind):
+    """BASELINE config 1 on the CPU oracle, computed once per session.  kind: 'fp64' (the exact reference),
+    'fp32', or 'emu' (fp32 arithmetic with bf16 storage at the HIP perf build's rounding points)."""
+    if kind not in _C1:
         shape = (2, 5, 3, 64, 64)
         sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 30, 4))
         lrs, hr, cot = rand(10, *shape), rand(11, 2, 5, 3, 256, 256), rand(13, 2, 5, 3, 256, 256, lo=-1, hi=1)
-        if emulate:
+        if kind == "emu":
             with O.emulate_bf16():
-                _C1[emulate] = O.fwd_bwd(sd, lrs, hr, cot=cot) + (hr,)
+                _C1[kind] = O.fwd_bwd(sd, lrs, hr, cot=cot) + (hr,)
+        elif kind == "fp64":
+            _C1[kind] = O.fwd_bwd({k: v.double() for k, v in sd.items()}, lrs.double(), hr.double(), cot=cot.double()) + (hr,)
         else:
-            _C1[emulate] = O.fwd_bwd(sd, lrs, hr, cot=cot) + (hr,)
-    return _C1[emulate]
+            _C1[kind] = O.fwd_bwd(sd, lrs, hr, cot=cot) + (hr,)
+    return _C1[kind]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_basicvsr_config1_all_grads_vs_oracle(dtype):
     """BASELINE config 1: n=2, t=5, 64x64 LR, BasicVSR(64, 30): sr, Charbonnier loss and EVERY
-    trainable gradient (254 tensors).  fp32 build vs the fp32 oracle; bf16 build vs the oracle that
-    emulates bf16 storage at the same points."""
+    trainable gradient (254 tensors).  fp32 build vs the fp32 oracle (1e-3 north-star bar on sr; gradients at the
+    oracle's own fp32-vs-fp64 noise floor).  bf16 build: error against the fp64 oracle <= 1.5 x the error of the
+    bf16-storage-emulating oracle against the same fp64 oracle, globally; per tensor <= 2.5 x (a single tensor's
+    mask-flip noise is itself a random draw; measured worst ratio in tests/gpu_diag.py)."""
     dev = _gpu()
     shape = (2, 5, 3, 64, 64)
     m, lrs, cot, sr, grads = _run_basicvsr(dtype, 64, 30, shape, 10, 13, dev)
-    sr_o, loss_o, grads_o, hr = _config1_oracle(dtype == "bf16")
-    assert rel_err(sr, sr_o) < tol(dtype, 1e-3, 6e-2)
     from vsrlab_amd.core.losses import CharbonnierLoss
-    loss = CharbonnierLoss()(sr.to(dev), hr.to(dev))
-    assert abs(float(loss) - float(loss_o)) < tol(dtype, 1e-4, 1e-2) * float(loss_o)
-    assert set(grads) == set(grads_o)
-    glob, worst, cos = _grad_report(grads, grads_o)
-    assert glob < tol(dtype, 2e-3, 2.5e-1), (glob, worst)
-    assert worst[0] < tol(dtype, 2e-2, 6e-1), worst
-    assert cos > tol(dtype, 0.99999, 0.97)
+    if dtype == "fp32":
+        sr_o, loss_o, grads_o, hr = _config1_oracle("fp32")
+        assert rel_err(sr, sr_o) < 1e-3
+        loss = CharbonnierLoss()(sr.to(dev), hr.to(dev))
+        assert abs(float(loss) - float(loss_o)) < 1e-4 * float(loss_o)
+        assert set(grads) == set(grads_o)
+        glob, worst, cos = _grad_report(grads, grads_o)
+        assert glob < 2e-3, (glob, worst)
+        assert worst[0] < 2e-2, worst
+        assert cos > 0.99999
+    else:
+        sr_x, loss_x, grads_x, hr = _config1_oracle("fp64")
+        sr_e, loss_e, grads_e, _ = _config1_oracle("emu")
+        assert set(grads) == set(grads_x)
+        assert rel_err(sr, sr_x) <= 1.5 * rel_err(sr_e, sr_x), (rel_err(sr, sr_x), rel_err(sr_e, sr_x))
+        loss = CharbonnierLoss()(sr.to(dev), hr.to(dev))
+        assert abs(float(loss) - float(loss_x)) <= 1.5 * max(abs(float(loss_e) - float(loss_x)), 1e-4 * float(loss_x))
+        _noise_floor_check(grads, grads_e, grads_x, max_glob_ratio=1.5, max_tensor_ratio=2.5)
+
+
+_C540 = {}
+
+
+def _oracle_540(kind):
+    """540x960, t=3, 2 blocks on the CPU oracle (fp32 arithmetic; 'emu' = with bf16 storage), once per session."""
+    if kind not in _C540:
+        shape = (1, 3, 3, 540, 960)
+        sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4))
+        lrs, cot = rand(70, *shape), rand(71, 1, 3, 3, 2160, 3840, lo=-1, hi=1)
+        if kind == "emu":
+            with O.emulate_bf16():
+                sr, _, g = O.fwd_bwd(sd, lrs, cot, cot=cot)
+        else:
+            sr, _, g = O.fwd_bwd(sd, lrs, cot, cot=cot)
+        _C540[kind] = (sr, g)
+    return _C540[kind]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_basicvsr_540p_vs_oracle(dtype):
+    """BASELINE config 2's frame size (540x960 -> 2160x3840) against the CPU oracle: t=3, 2 blocks, sr and all 30
+    gradients.  Exercises ragged tile rows (540 = 67.5 x 8), the 2160x3840 HR kernels, the multi-frame wgrad launches
+    and the arena offsets at this size.  fp32: north-star 1e-3 on sr, gradients at the fp32 noise floor; bf16: error <=
+    1.5 x the emulation's own error against the fp32 oracle (global), 2.5 x per tensor."""
+    dev = _gpu()
+    shape = (1, 3, 3, 540, 960)
+    m, lrs, cot, sr, grads = _run_basicvsr(dtype, 64, 2, shape, 70, 71, dev)
+    sr_o, g_o = _oracle_540("fp32")
+    assert set(grads) == set(g_o)
+    if dtype == "fp32":
+        assert rel_err(sr, sr_o) < 1e-3
+        glob, worst, cos = _grad_report(grads, g_o)
+        assert glob < 2e-3, (glob, worst)
+        assert worst[0] < 2e-2, worst
+    else:
+        sr_e, g_e = _oracle_540("emu")
+        assert rel_err(sr, sr_o) <= 1.5 * max(rel_err(sr_e, sr_o), 1e-3)
+        _noise_floor_check(grads, g_e, g_o, max_glob_ratio=1.5, max_tensor_ratio=2.5)
+    m._pool.clear()
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 at FULL size through the C ABI (n=1, t=7, 540x960, 30 blocks, bf16: the benchmarked
+    configuration, ~128 GiB arena): finite outputs; a second backward on the same retained forward reproduces the
+    reconstruction gradients bit for bit (they are computed before any warp scatter) and every other tensor to
+    atomic-order noise; the backward is linear in the cotangent.  One forward, four backwards."""
+    dev = _gpu()
+    import vsrlab_amd
+    from vsrlab_amd import functional as VF
+    from vsrlab_amd._order import basicvsr_keys
+    lib = vsrlab_amd._lib.load()
+    n, t, h, w, rb = 1, 7, 540, 960, 30
+    sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, rb, 4))
+    keys, n_train = basicvsr_keys(rb)
+    ps = [sd[k].to(dev).contiguous() for k in keys]
+    desc = vsrlab_amd._lib.BasicVSRDesc(n, t, h, w, 64, rb, 4, VF.DT_BF16)
+    nbytes = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(desc), 1)
+    assert nbytes > 100 * 2**30
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    lrs = torch.rand(n, t, 3, h, w, device=dev)
+    sr = torch.empty(n, t, 3, 4 * h, 4 * w, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.vsr_basicvsr_forward(ctypes.byref(desc), VF._ptr_array(ps), len(ps), VF._ptr(lrs), VF._ptr(sr), VF._ptr(ws), nbytes, 1, st) == 0
+    assert bool(torch.isfinite(sr).all())
+    # same weights, frame 0 alone at inference (no arena retention): the first frame of the backward-time chain differs
+    # (it sees the later frames), so only shapes / finiteness are compared here; values are pinned at t=3 above.
+
+    def bwd(cot):
+        gs = [torch.zeros_like(p) if k < n_train else None for k, p in enumerate(ps)]
+        assert lib.vsr_basicvsr_backward(ctypes.byref(desc), VF._ptr_array(ps), VF._ptr_array(gs), len(ps), VF._ptr(lrs), VF._ptr(cot),
+                                         VF._ptr(None), VF._ptr(ws), nbytes, st) == 0
+        return {keys[k]: g for k, g in enumerate(gs) if g is not None}
+
+    c1 = torch.randn_like(sr)
+    c2 = torch.randn_like(sr)
+    g1, g1b, g2 = bwd(c1), bwd(c1), bwd(c2)
+    c12 = 0.5 * c1 + c2
+    g12 = bwd(c12)
+    del c12
+    assert len(g1) == n_train == 254
+    recon = [k for k in g1 if k.startswith(("conv_last", "upsample", "point_conv"))]
+    assert len(recon) == 10
+    for k in g1:
+        assert bool(torch.isfinite(g1[k]).all()) and float(g1[k].abs().max()) > 0, k
+        if k in recon:
+            assert torch.equal(g1[k], g1b[k]), k                 # no atomics upstream of these
+        else:
+            assert rel_l2(g1b[k], g1[k]) < 2e-3, k               # warp scatter: fp32 atomic order noise only
+    cat = lambda d: torch.cat([d[k].flatten() for k in sorted(d)])
+    # every product dY*X is formed from bf16-rounded activation gradients: linear up to bf16 rounding
+    assert rel_l2(cat(g12), 0.5 * cat(g1) + cat(g2)) < 3e-2
+    del ws
 
 
 def test_ragged_sizes_and_single_frame():

@@ -4,10 +4,11 @@
 //   * boundary tensors (what PyTorch sees): LR clip / SR clip / cotangents are planar
 //     fp32 NCHW, parameters and their gradients are fp32 OIHW -- exactly the reference's
 //     tensors (basicvsr.py:39-83).
-//   * everything internal to the path is "pixel-major": [N][H][W][C] with C a multiple of
-//     16, element type T = bf16 (perf build) or fp32 (parity build).  One 64-channel pixel
-//     in bf16 is exactly one 128-byte line, so tile rows are long contiguous bursts and an
-//     MFMA B-fragment (8 consecutive channels of one pixel) is one 16-byte LDS read.
+//   * everything internal to the path is "pixel-major", BLOCKED by 32 pixels:
+//     [N][H][ceil(W/32)][C/8][32 pixels][8 channels] (pm_off() below), C a multiple of 16,
+//     element type T = bf16 (perf build) or fp32 (parity build): the MFMA accumulator layout
+//     of the conv kernels, so epilogues store / read residuals with 512-byte wave instructions;
+//     an MFMA B-fragment (8 consecutive channels of one pixel) is still one 16-byte piece.
 //   * optical flow is planar fp32 [N][2][H][W] (channel 0 = dx), coalesced along x.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -126,6 +127,35 @@ static inline __device__ TileWalk xcd_tile_walk(int total, int block, int nblock
         w.first = block; w.end = total; w.stride = nblocks;
     }
     return w;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process that drives several GPUs must
+// apply it on each of them, so "done" is remembered per (kernel, device).  Set twice by two racing threads = harmless.
+#define VSR_MAX_DEVICES 32
+struct VsrDevOnce { bool done[VSR_MAX_DEVICES] = {}; };
+static inline int vsr_set_max_dynamic_lds(VsrDevOnce& once, const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VSR_ERR_HIP;
+    if (dev < 0 || dev >= VSR_MAX_DEVICES) return VSR_ERR_UNSUPPORTED;
+    if (!__atomic_load_n(&once.done[dev], __ATOMIC_ACQUIRE)) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return VSR_ERR_HIP;
+        __atomic_store_n(&once.done[dev], true, __ATOMIC_RELEASE);
+    }
+    return VSR_OK;
+}
+
+// compute units of the current device (cached per device; hipGetDeviceProperties costs ~a millisecond)
+static inline int vsr_num_cus() {
+    static int cus[VSR_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VSR_MAX_DEVICES) return 256;
+    int v = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        __atomic_store_n(&cus[dev], v, __ATOMIC_RELAXED);
+    }
+    return v;
 }
 
 #define HIP_CHECK_RET(expr)                                   \

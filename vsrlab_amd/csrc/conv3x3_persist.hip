@@ -5,16 +5,16 @@
 // At 540p one launch moves 133-200 MB for 38 GFLOP: 21-32 us at the 6.3 TB/s a CU-side stream reaches,
 // 15 us on the matrix cores -- the kernel is HBM-bound, and a CU needs ~75 KB in flight to cover ~3 us of
 // loaded HBM latency.  Design for one MI355X CU (160 KiB LDS, 4 SIMDs):
-//   * ONE 256-thread workgroup per CU (one wave per SIMD, up to 512 VGPRs each), grid = #CUs, persistent
-//     over 8x32-pixel tiles (one 32-pixel segment of the blocked layout wide, see common.h).  The packed
-//     weights [9 taps][64 cout][64 cin] bf16 (72 KiB) are loaded into LDS once and stay.
-//   * the haloed 10x34-pixel input tile is DOUBLE-BUFFERED in LDS (2 x 42.5 KiB) and filled by LDS-DMA
-//     (global_load_lds_dwordx4) one whole tile ahead; the residual / mask operands of the epilogue are
-//     requested into registers before the K loop.  Nothing the tile needs is waited for at first use.
-//   * K loop: 144 v_mfma_f32_32x32x16_bf16 per wave and tile, no barrier inside; A (weights) and B (pixels)
-//     fragments are ds_read_b128 at register base + immediate, issued by hand two k-steps ahead of their
-//     MFMAs (inline asm + counted s_waitcnt: a lone wave per SIMD has nobody to hide an LDS round trip
-//     behind, and hipcc sinks builtin LDS reads back in front of their consumers).  The weight image is
+//   * ONE 512-thread workgroup per CU, grid = #CUs, persistent over 8x32-pixel tiles (one 32-pixel segment
+//     of the blocked layout wide, see common.h): 4 MFMA waves + 4 LDS-DMA producer waves, one of each per
+//     SIMD.  The packed weights [9 taps][64 cout][64 cin] bf16 (72 KiB) are loaded into LDS once and stay.
+//   * the haloed 10x34-pixel input tile is DOUBLE-BUFFERED in LDS (2 x 42.5 KiB) and filled by the producer
+//     waves' LDS-DMA (global_load_lds_dwordx4) one whole tile ahead; the residual / mask operands of the
+//     epilogue are requested into registers before the K loop.  Nothing the tile needs is waited for at first use.
+//   * K loop: 288 v_mfma_f32_16x16x32_bf16 per MFMA wave and tile, no barrier inside; A (weights) and B (pixels)
+//     fragments are ds_read_b128 at register base + immediate, issued by hand one k-step ahead of their
+//     MFMAs (inline asm + counted s_waitcnt: hipcc sinks builtin LDS reads back in front of their
+//     consumers).  The weight image is
 //     [cout row][8 chunks of 16 B], XOR-swizzled on the chunk; the pixel image mirrors the blocked global
 //     layout, [tile row][chunk][34 pixels][16 B]: 16 consecutive lanes read 16 consecutive 16-byte slots
 //     (conflict-free without a swizzle), a ky shift is an immediate, and a DMA piece reads runs of up to 512
@@ -360,11 +360,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 template <int ACT, bool HAS_RES, int MASK>
 static int launch_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
     auto kern = conv3x3_c64_persist_kernel<ACT, HAS_RES, MASK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
-        attr_set = true;
-    }
+    static VsrDevOnce once;                                 // one per instantiation, remembered per device
+    { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), P_LDS); if (rc != VSR_OK) return rc; }
     const int tiles = a.N * cdiv(a.W, PTW) * cdiv(a.H, PTH);
     int gx = num_cus / a.nz;
     if (gx < 1) gx = 1;

@@ -347,11 +347,8 @@ int launch_inst(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = THH * TWH * (CMAX / 8) * CHB + 2 * COUT * (CMAX / 8) * CHB;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS of a CU");
     auto kern = conv_mfma_kernel<T, KS, NSRC, CA, CB, LP, COUT, EPI>;
-    static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static VsrDevOnce once;
+    { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), LDS); if (rc != VSR_OK) return rc; }
     dim3 grid(cdiv(a.W, TW), cdiv(a.H, TH), a.N * a.nz);
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS, st, a);
     HIP_CHECK_RET(hipGetLastError());
@@ -398,15 +395,7 @@ int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar
          (a.in_step == 2 && a.Hs == 2 * a.H && a.Ws == 2 * a.W && (unsigned)a.src_oy[0] < 2u && (unsigned)a.src_ox[0] < 2u)) &&
         a.CD == 64 && a.cout_real == 64 &&
         a.src[0] != nullptr && !vsr_force_generic_conv()) {
-        static int num_cus = 0;
-        if (num_cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            HIP_CHECK_RET(hipGetDevice(&dev));
-            HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
-            num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-        const int ps = vsr_launch_conv3x3_c64_persist(a, num_cus, st);
+        const int ps = vsr_launch_conv3x3_c64_persist(a, vsr_num_cus(), st);
         if (ps != VSR_ERR_UNSUPPORTED) return ps;
     }
     // 64 -> (<= 4) channels with a planar destination: streaming kernel of hr_tail.hip

@@ -1056,21 +1056,28 @@ int vsr_cleaner_backward(int F, int h, int w, int mid_channels, int blocks, int 
 }
 
 // ---- per-op entry points -------------------------------------------------------------------------
+static bool bad_dtype(int dtype) { return dtype != VSR_F32 && dtype != VSR_BF16; }
+static bool bad_dims(int N, int H, int W) { return N < 1 || H < 1 || W < 1; }
+
 int vsr_flow_warp_fwd(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H, int W, int Cc, void* stream) {
+    if (bad_dtype(dtype) || !in_pm || !flow || !out_pm || bad_dims(N, H, W) || Cc < 16 || (Cc & 15)) return VSR_ERR_BADARG;
     return vsr_launch_warp_fwd(dtype, in_pm, flow, out_pm, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
 }
 int vsr_flow_warp_bwd(int dtype, const void* dout_pm, const float* flow, float* dacc, int N, int H, int W, int Cc, void* stream) {
+    if (bad_dtype(dtype) || !dout_pm || !flow || !dacc || bad_dims(N, H, W) || Cc < 16 || (Cc & 15)) return VSR_ERR_BADARG;
     return vsr_launch_warp_bwd(dtype, dout_pm, flow, dacc, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
 }
 int vsr_flow_warp_bwd_flow(int dtype, const void* in_pm, const void* dout_pm, const float* flow, float* dflow, int N, int H, int W,
                            int Cc, void* stream) {
-    if (!in_pm || !dout_pm || !flow || !dflow || N < 1 || H < 1 || W < 1) return VSR_ERR_BADARG;
+    if (bad_dtype(dtype) || !in_pm || !dout_pm || !flow || !dflow || bad_dims(N, H, W) || Cc < 16 || (Cc & 15)) return VSR_ERR_BADARG;
     return vsr_launch_warp_bwd_flow(dtype, in_pm, dout_pm, flow, dflow, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
 }
 int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int Cc, void* stream) {
+    if (bad_dtype(dtype) || !in || !out_pm || bad_dims(N, H, W) || Cin < 1 || Cc < Cin || (Cc & 15)) return VSR_ERR_BADARG;
     return vsr_launch_planar_to_pm(dtype, in, out_pm, N, Cin, H, W, Cc, (hipStream_t)stream);
 }
 int vsr_pm_to_planar(int dtype, const void* in_pm, float* out, int N, int Cout, int H, int W, int Cc, void* stream) {
+    if (bad_dtype(dtype) || !in_pm || !out || bad_dims(N, H, W) || Cout < 1 || Cc < Cout || (Cc & 15)) return VSR_ERR_BADARG;
     return vsr_launch_pm_to_planar(dtype, in_pm, out, N, Cout, H, W, Cc, (hipStream_t)stream);
 }
 
@@ -1084,6 +1091,7 @@ static ConvArgs plain64(const void* x, const void* wpack, const float* b, void* 
 
 int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float* b, void* wpack, void* y_pm, const void* res_pm,
                         int act, int N, int H, int W, void* stream) {
+    if (bad_dtype(dtype) || !x_pm || !wpack || !y_pm || bad_dims(N, H, W) || act < ACT_NONE || act > ACT_LEAKY) return VSR_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (w) CK(vsr_launch_pack_weights(dtype, w, wpack, 9, C, C, C, C, C, 0, 1, 0, 0, st));   // w == NULL: wpack already packed
     ConvArgs a = plain64(x_pm, wpack, b, y_pm, N, H, W);
@@ -1093,6 +1101,9 @@ int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float
 
 int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm, const void* res_pm,
                           const void* aux_pm, int mask_mode, int N, int H, int W, void* stream) {
+    if (bad_dtype(dtype) || !dy_pm || !w || !wpack || !dx_pm || bad_dims(N, H, W) || mask_mode < MASK_NONE || mask_mode > MASK_LEAKY ||
+        (mask_mode != MASK_NONE && !aux_pm))
+        return VSR_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
     CK(vsr_launch_pack_weights(dtype, w, wpack, 9, C, C, C, C, C, 0, 1, 0, 1, st));
     ConvArgs a = plain64(dy_pm, wpack, nullptr, dx_pm, N, H, W);
@@ -1108,6 +1119,7 @@ size_t vsr_conv3x3_c64_wgrad_slab_floats(void) {
 
 int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float* gw, float* gb, float* slab, int N, int H, int W,
                           void* stream) {
+    if (bad_dtype(dtype) || !x_pm || !dy_pm || !gw || !slab || bad_dims(N, H, W)) return VSR_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a = wg_base(N, H, W);
     a.x[0] = x_pm; a.dy[0] = dy_pm;

@@ -435,17 +435,9 @@ int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st) {
         a.Hs != a.H || a.Ws != a.W || a.out_step != 1 || a.Hd != a.H || a.Wd != a.W || !a.src[0] || a.aux[0] || a.res[0])
         return VSR_ERR_UNSUPPORTED;
     if (pm_image_elems(LT_H + 4, a.Ws, 64) * 2 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;     // in-tile source offsets are 32-bit
-    static bool attr_set = false;
-    static int num_cus = 0;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(c64_to_planar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FP_TILE));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        HIP_CHECK_RET(hipGetDevice(&dev));
-        HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        attr_set = true;
-    }
+    static VsrDevOnce once;
+    { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(c64_to_planar_kernel), 2 * FP_TILE); if (rc != VSR_OK) return rc; }
+    const int num_cus = vsr_num_cus();
     const int tiles = a.N * cdiv(a.W, LT_W) * cdiv(a.H, LT_H);
     const int grid = tiles < num_cus ? tiles : num_cus;
     hipLaunchKernelGGL(c64_to_planar_kernel, dim3(grid), dim3(FP_NT), 2 * FP_TILE, st, a);
@@ -460,17 +452,9 @@ int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride,
     if (!x || !dy || !slab || !nslabs || N < 1 || H < 1 || W < 1) return VSR_ERR_BADARG;
     if (pm_image_elems(LT_H + 4, W, 64) * 2 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;
     constexpr int LDS = (3 * 144 * 64 + 4 * 64) * 4 > 2 * LW_TILE ? (3 * 144 * 64 + 4 * 64) * 4 : 2 * LW_TILE;     // 111,616 B
-    static bool attr_set = false;
-    static int num_cus = 0;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(last2_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        HIP_CHECK_RET(hipGetDevice(&dev));
-        HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        attr_set = true;
-    }
+    static VsrDevOnce once;
+    { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(last2_wgrad_kernel), LDS); if (rc != VSR_OK) return rc; }
+    const int num_cus = vsr_num_cus();
     const int tiles = N * cdiv(W, LT_W) * cdiv(H, LT_H);
     const int grid = tiles < num_cus ? tiles : num_cus;
     *nslabs = grid;
