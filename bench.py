@@ -7,9 +7,12 @@
 
 One "step" = one pass of the hot path over one synthetic clip per GPU: HIP forward of
 BasicVSR(64, 30, 4) on (1,7,3,540,960), fused Charbonnier loss + its gradient, HIP backward (all
-weight gradients), DDP gradient all-reduce over RCCL when N > 1, and an Adam step (kept inside the
-timed region so that no training work is skipped).  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0.
+weight gradients, written straight into the optimizer's flat gradient arena), ONE RCCL all-reduce of
+that arena when N > 1, and the reference's update_weights tail (core/utils.py:270-280:
+clip_grad_norm_(1) + Adam + zero_grad) as the fused HIP step -- kept inside the timed region so that
+no training work is skipped.  `--optimizer torch --dp ddp` runs the reference's own stack instead
+(torch.optim.Adam, DistributedDataParallel).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -76,33 +79,42 @@ def flops_per_frame(h, w, t, rb):
     return f
 
 
-def dominant_kernel_roofline(dev, h, w, iters=40):
+def dominant_kernel_roofline(dev, h, w, iters=48, nsets=8):
     """conv3x3_c64_persist_kernel (bf16, 3x3, 64->64): the trunk/reconstruction conv and its data
     gradient (>70% of the path's FLOPs).  Timed with HIP events on the stream it is launched on
     (torch's current stream), same shape and epilogues as inside the engine.  Algorithmic bytes per
-    launch: X 64*P*2 + Y 64*P*2 (+ skip 64*P*2 on every second launch)."""
+    launch: X 64*P*2 + Y 64*P*2 (+ skip 64*P*2 on every second launch).
+    The launches rotate through `nsets` = 8 distinct (x, skip, y) buffer sets = 1.6 GB at 540p, far beyond the 256 MiB
+    Infinity Cache, so no operand of a launch is cache-resident from an earlier one (round-1 ADVICE: three 66 MB
+    buffers were L3-resident and flattered the number)."""
     from vsrlab_amd import functional as VF
-    x = VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16)
-    r = VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16)
+    xs = [VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16) for _ in range(nsets)]
+    rs = [VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16) for _ in range(nsets)]
+    ys = [torch.empty_like(xs[0]) for _ in range(nsets)]
     wgt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
     b = torch.zeros(64, device=dev)
     for _ in range(3):
-        VF.conv3x3_c64(x, wgt, b, act=1)
+        VF.conv3x3_c64(xs[0], wgt, b, act=1)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lib = __import__("vsrlab_amd")._lib.load()
     import ctypes
     wpack = torch.empty(9 * 64 * 64, dtype=torch.bfloat16, device=dev)
-    y = torch.empty_like(x)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     # weights are packed by the first call (w given); the timed launches pass w = NULL, so the events bracket
     # conv3x3_c64_persist_kernel launches only, alternating the two trunk epilogues (bias+ReLU / bias+skip)
-    lib.vsr_conv3x3_c64_fwd(1, VF._ptr(x), VF._ptr(wgt), VF._ptr(b), VF._ptr(wpack), VF._ptr(y), VF._ptr(None), 1, 1, h, w, st)
+    lib.vsr_conv3x3_c64_fwd(1, VF._ptr(xs[0]), VF._ptr(wgt), VF._ptr(b), VF._ptr(wpack), VF._ptr(ys[0]), VF._ptr(None), 1, 1, h, w, st)
+
+    def launch(i):
+        k = i % nsets
+        lib.vsr_conv3x3_c64_fwd(1, VF._ptr(xs[k]), VF._ptr(None), VF._ptr(b), VF._ptr(wpack), VF._ptr(ys[k]), VF._ptr(rs[k] if i & 1 else None),
+                                1 if not (i & 1) else 0, 1, h, w, st)
+    for i in range(nsets):
+        launch(i)
     torch.cuda.synchronize()
     e0.record()
     for i in range(iters):
-        lib.vsr_conv3x3_c64_fwd(1, VF._ptr(x), VF._ptr(None), VF._ptr(b), VF._ptr(wpack), VF._ptr(y), VF._ptr(r if i & 1 else None),
-                                1 if not (i & 1) else 0, 1, h, w, st)
+        launch(i)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -110,16 +122,22 @@ def dominant_kernel_roofline(dev, h, w, iters=40):
     alg_bytes = (64 + 64) * P * 2 + 0.5 * 64 * P * 2          # X + Y (+ skip read on every second launch)
     flops = 2.0 * P * 64 * 576
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    traffic = None                     # HBM bytes per launch from PMC (FETCH_SIZE x2 + WRITE_SIZE), measured with rocprofv3
+    out = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "traffic": None, "kernel": "conv3x3_c64_persist_kernel<ACT,RES,MASK> (bias+ReLU / bias+skip alternating, 8 rotating 66 MB buffer sets)",
+           "avg_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bytes, "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+           "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+    # From committed rocprofv3 runs of THIS command (profiles/README.md): HBM bytes per launch from the PMC passes
+    # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section), the MFMA-busy counters, and the same kernel's
+    # call-weighted figure inside one timed step of the single-stream kernel trace.
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        traffic = 0.5 * (tj["conv3x3_c64_persist<relu>"]["hbm_bytes_per_launch"] + tj["conv3x3_c64_persist<skip>"]["hbm_bytes_per_launch"])
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline.json")))
+        out["traffic"] = pj.get("hbm_bytes_per_launch")
+        for k in ("in_step", "mfma_busy"):
+            if k in pj:
+                out[k] = pj[k]
     except Exception:
         pass
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "kernel": "conv3x3_c64_persist_kernel<ACT,RES,MASK> (bias+ReLU / bias+skip alternating)", "avg_us": round(ms * 1e3, 2),
-            "algorithmic_bytes_per_launch": alg_bytes, "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
-            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+    return out
 
 
 def host_cores():
@@ -137,16 +155,18 @@ def log(msg):
 
 
 def cpu_baseline(h540, w540):
-    """The oracle (CPU restatement of the reference, fp32) on this box's host cores, on a bounded
-    sample: BASELINE config 1 (n=2,t=5,64x64, rb=30), fwd+Charbonnier+bwd, best of 2 after a warm-up."""
+    """The oracle (CPU restatement of the reference, fp32, "port") on this box's host cores, on a bounded sample
+    (BASELINE.md section 4): (i) BASELINE config 1 exactly (n=2, t=5, 64x64, rb=30) fwd+Charbonnier+bwd, best of 2
+    after a warm-up; (ii) one 540x960 frame (n=1, t=1, rb=30) fwd+Charbonnier+bwd, ONE run -- the frame size the
+    metric is quoted on; a 7-frame clip needs > 113 GB of saved fp32 activations and minutes of CPU time, and the cost
+    is linear in n*t*pixels.  value = (ii)'s LR frames/s."""
     from oracle import basicvsr_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 30, 4))
     g = torch.Generator().manual_seed(0)
-    hs, ws = 128, 128                          # config-1 clip at 4x the pixels: ~4-5 s per step on 16 cores, ~15 s in all
-    lrs = torch.rand(2, 5, 3, hs, ws, generator=g)
-    hr = torch.rand(2, 5, 3, 4 * hs, 4 * ws, generator=g)
+    lrs = torch.rand(2, 5, 3, 64, 64, generator=g)
+    hr = torch.rand(2, 5, 3, 256, 256, generator=g)
     best = None
     for i in range(3):
         t0 = time.perf_counter()
@@ -154,11 +174,17 @@ def cpu_baseline(h540, w540):
         dt = time.perf_counter() - t0
         if i > 0:
             best = dt if best is None else min(best, dt)
-    fps_small = 10.0 / best
-    fps_540 = fps_small * (hs * ws) / float(h540 * w540)
-    return {"value": round(fps_540, 5), "unit": "LR frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 fwd+Charbonnier+bwd on n=2,t=5,{hs}x{ws} LR (rb=30), best of 2 after a warm-up: {best:.2f}s/step = "
-                      f"{fps_small:.2f} frames/s at {hs}x{ws}; value = per-pixel-normalised to {h540}x{w540} (cost is linear in pixels)"}
+    fps_c1 = 10.0 / best
+    lrs = torch.rand(1, 1, 3, h540, w540, generator=g)
+    hr = torch.rand(1, 1, 3, 4 * h540, 4 * w540, generator=g)
+    t0 = time.perf_counter()
+    O.fwd_bwd(sd, lrs, hr)
+    dt540 = time.perf_counter() - t0
+    return {"value": round(1.0 / dt540, 5), "unit": "LR frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 fwd+Charbonnier+bwd, rb=30: (i) config 1 (n=2,t=5,64x64) best of 2 after a warm-up {best:.2f} s/step = "
+                      f"{fps_c1:.2f} LR frames/s at 64x64 (= {fps_c1 * 64 * 64 / float(h540 * w540):.4f} per-pixel-normalised to {h540}x{w540}); "
+                      f"(ii) one {h540}x{w540} frame (n=1,t=1), one run: {dt540:.1f} s = value",
+            "config1_frames_per_s": round(fps_c1, 3)}
 
 
 def main():
@@ -172,7 +198,14 @@ def main():
     ap.add_argument("--res-blocks", type=int, default=30)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="fused: vsrlab_amd.optim.FusedAdam (clip + Adam over flat arenas); torch: torch.optim.Adam (no clipping), the round-1 step")
+    ap.add_argument("--dp", default="flat", choices=["flat", "ddp"],
+                    help="N > 1: flat = one all-reduce over the gradient arena (vsrlab_amd.parallel.FlatGradSync); ddp = torch DistributedDataParallel")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel leg (for rocprofv3 PMC passes)")
     args = ap.parse_args()
+    if args.optimizer == "torch" and args.dp == "flat":
+        args.dp = "ddp"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -182,6 +215,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.roofline_only:
+        print(json.dumps(dominant_kernel_roofline(dev, args.height, args.width)), flush=True)
+        return
     dist = None
     use_dist = world > 1 or "RANK" in os.environ     # under torchrun even a 1-rank job takes the DDP / RCCL path
     if use_dist:
@@ -197,10 +233,19 @@ def main():
     model = BasicVSR(64, args.res_blocks, 4, False, False).to(dev)
     model.compute_dtype = args.dtype
     net = model
-    if use_dist:
-        from torch.nn.parallel import DistributedDataParallel
-        net = DistributedDataParallel(model, device_ids=[local_rank])       # core/utils.py:147-151
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)   # conf/train/optimizer/adam.yaml
+    sync = None
+    if args.optimizer == "fused":
+        from vsrlab_amd.optim import FusedAdam
+        # conf/train/optimizer/adam.yaml (lr 1e-4, betas (0.9, 0.99), eps 1e-8) + gradient_clip_val: 1 (conf/train/default.yaml:20)
+        opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0)
+        if use_dist:
+            from vsrlab_amd.parallel import FlatGradSync
+            sync = FlatGradSync(opt.flat_grads, params=opt.flat_params)    # start-up broadcast + one all-reduce per step
+    else:
+        if use_dist:
+            from torch.nn.parallel import DistributedDataParallel
+            net = DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, broadcast_buffers=False)  # core/utils.py:147-151
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
     crit = CharbonnierLoss()
     n, t, h, w = 1, args.frames, args.height, args.width
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)             # one distinct clip per rank (weak scaling)
@@ -208,11 +253,13 @@ def main():
     hr = torch.rand(n, t, 3, 4 * h, 4 * w, generator=g).to(dev)
 
     def step():
-        opt.zero_grad(set_to_none=True)
         sr = net(lrs)
         loss = crit(sr, hr)
         loss.backward()
+        if sync is not None:
+            sync.all_reduce()
         opt.step()
+        opt.zero_grad(set_to_none=(args.optimizer == "torch"))
         return loss
 
     for i in range(args.warmup):
@@ -246,11 +293,12 @@ def main():
             "value": round(frames_per_s, 3), "unit": "LR frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (torch.rand clips, random-init weights)",
-            "config": {"workload": f"BasicVSR(mid=64,res_blocks={args.res_blocks},x4) fwd+Charbonnier+bwd+Adam, "
+            "config": {"workload": f"BasicVSR(mid=64,res_blocks={args.res_blocks},x4) fwd+Charbonnier+bwd+clip+Adam, "
                                    f"{h}x{w}->{4 * h}x{4 * w}, {t}-frame clip, 1 clip per GPU (BASELINE configs[1]{'/[3]' if world > 1 else ''})",
                        "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "res_blocks": args.res_blocks,
-                       "parallelism": f"dp{world} (clip-level, DDP grad all-reduce over RCCL)" if world > 1 else "single GPU",
-                       "optimizer_in_timed_region": "adam"},
+                       "parallelism": (f"dp{world} (clip-level; " + ("one RCCL all-reduce of the flat gradient arena per step)" if sync is not None
+                                                                        else "DDP grad all-reduce over RCCL)")) if world > 1 else "single GPU",
+                       "optimizer_in_timed_region": "fused clip_grad_norm(1)+Adam (HIP)" if args.optimizer == "fused" else "torch.optim.Adam"},
             "loss": round(loss_val, 6),
         }
         bpf = algorithmic_bytes_per_frame(h, w, t, args.res_blocks, 2 if args.dtype == "bf16" else 4)

@@ -162,6 +162,27 @@ int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float*
 int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, long long numel,
                             float eps, void* stream);
 
+/* ---- training-step glue over FLAT fp32 arenas (csrc/train_step.hip) ---------------------------------------
+ * Replaces the reference's `update_weights` tail (core/utils.py:270-280): clip_grad_norm_(model.parameters(),
+ * grad_clip) + torch.optim.Adam.step() (conf/train/optimizer/adam.yaml), for a model whose parameters, gradients
+ * and Adam moments each live in ONE contiguous, 16-byte-aligned fp32 buffer of `numel` elements (the HIP backward
+ * writes all gradients into such an arena).  scratch: vsr_optim_scratch_floats() floats.
+ *   total_norm = |grad_scale| * ||grads||_2                        -> norm_out[0] (device, optional)
+ *   g' = grad_scale * min(1, max_norm / (total_norm + 1e-6)) * g   (max_norm <= 0: no clipping) (+ weight_decay * p)
+ *   exp_avg, exp_avg_sq, params updated with torch.optim.Adam's formulas for step number `step` (1-based).
+ * `grads` is not modified (clip_grad_norm_ scales it in place; the reference zeroes it right after the step).
+ * A non-finite total_norm leaves params and moments untouched (GradScaler.step's behaviour, train.py:74).   */
+size_t vsr_optim_scratch_floats(void);
+int vsr_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long numel,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                       float max_norm, float* scratch, float* norm_out, void* stream);
+/* norm_out[0] = |grad_scale| * ||grads||_2 alone (clip_grad_norm_'s return value). */
+int vsr_grad_norm(const float* grads, long long numel, float grad_scale, float* scratch, float* norm_out, void* stream);
+
+/* out (planes,h,w) = bilinear resize of in (planes,H,W), align_corners=False, no antialiasing: kornia's
+ * resize(hr, (h, w)) in compute_loss (core/utils.py:235-240), the target of the pre-clean stack's loss term.  */
+int vsr_resize_bilinear(const float* in, float* out, long long planes, int H, int W, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

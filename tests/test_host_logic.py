@@ -170,3 +170,92 @@ def test_ddp_gloo_world2_gradients_are_the_mean_over_ranks(tmp_path):
         grads.append(torch.cat([leaves[k].grad.flatten() for k in order]))
     want = 0.5 * (grads[0] + grads[1])
     assert float((got["g"] - want).abs().max() / want.abs().max()) < 1e-5
+
+
+# ---- MI355X-first data-parallel path: ONE all-reduce over the flat gradient arena per optimizer step ----
+def _flat_sync_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from vsrlab_amd import functional as VF
+        from vsrlab_amd.core.utils import update_weights
+        from vsrlab_amd.parallel import FlatGradSync
+        from vsrlab_amd.vsr.models.RealBasicVSR.modules import basicvsr as mod
+
+        def fake_engine(lrs, params, n_trainable, mid, rb, up, pool, compute_dtype=None):     # TEST ONLY, see _ddp_worker
+            from vsrlab_amd._order import basicvsr_keys
+            keys, _ = basicvsr_keys(rb, up)
+            return O.basicvsr_forward(dict(zip(keys, params)), lrs)
+
+        VF.basicvsr_forward = fake_engine
+        torch.manual_seed(200 + rank)                      # different init per rank: the start-up broadcast must fix it
+        m = mod.BasicVSR(64, 1, 4, False, False)
+        train = [p for p in m.parameters() if p.requires_grad]
+        # the arenas FusedAdam builds on the GPU, restated with CPU tensors (the optimizer itself has no CPU path)
+        n = sum(p.numel() for p in train)
+        flat_p, flat_g = torch.zeros(n), torch.zeros(n)
+        o = 0
+        with torch.no_grad():
+            for p in train:
+                flat_p[o:o + p.numel()].copy_(p.reshape(-1))
+                p.data = flat_p[o:o + p.numel()].view(p.shape)
+                p.grad = flat_g[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+        sync = FlatGradSync(flat_g, params=flat_p)
+        w0 = flat_p.clone()
+        opt = torch.optim.SGD(train, lr=0.1)
+        opt.zero_grad = lambda *a, **k: flat_g.zero_()    # keep the .grad views (what FusedAdam.zero_grad does)
+        num_grad_acc = 2
+        for i in range(num_grad_acc):                      # conf/experiment/basic.yaml:26 style accumulation
+            lrs = torch.rand(1, 2, 3, 8, 8, generator=torch.Generator().manual_seed(31 + 10 * rank + i))
+            loss = m(lrs).mean()
+            if i == num_grad_acc - 1:
+                g_before = None
+            update_weights(m, loss, None, None, opt, num_grad_acc, 1e9, i, grad_sync=sync)
+            if i == 0:
+                assert sync.num_collectives == 0           # no_sync on the non-final micro-step
+        assert sync.num_collectives == 1
+        ws = [torch.zeros_like(flat_p) for _ in range(world)]
+        dist.all_gather(ws, flat_p)
+        assert torch.equal(ws[0], ws[1])                   # replicas stay identical
+        if rank == 0:
+            torch.save({"w0": w0, "w1": flat_p.clone(), "sd": {k: v.clone() for k, v in m.state_dict().items()}}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_sync_gloo_world2_with_accumulation_and_no_sync(tmp_path):
+    out = str(tmp_path / "rank0.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_flat_sync_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    # expected update: w1 = w0 - lr * mean over ranks of sum over micro-steps of grad(loss / num_grad_acc), from rank 0's weights
+    from vsrlab_amd._order import basicvsr_keys
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules import basicvsr as mod
+    torch.manual_seed(200)
+    m = mod.BasicVSR(64, 1, 4, False, False)
+    sd0 = m.state_dict()
+    keys, n_train = basicvsr_keys(1)
+    order = [k for k, p in m.named_parameters() if p.requires_grad]
+    total = None
+    for r in range(2):
+        for i in range(2):
+            leaves = {k: v.clone().requires_grad_(k in set(order)) for k, v in sd0.items()}
+            lrs = torch.rand(1, 2, 3, 8, 8, generator=torch.Generator().manual_seed(31 + 10 * r + i))
+            (O.basicvsr_forward(leaves, lrs).mean() / 2).backward()
+            g = torch.cat([leaves[k].grad.flatten() for k in order])
+            total = g if total is None else total + g
+    upd, want = got["w1"] - got["w0"], -0.1 * (total / 2)
+    assert float((upd - want).norm() / want.norm()) < 1e-3            # fp32 noise of two CPU evaluations (2 vs N threads)
+    assert float((got["w0"] - torch.cat([sd0[k].flatten() for k in order])).abs().max()) == 0.0   # rank 0's weights were broadcast
+
+
+def test_training_glue_has_no_cpu_fallback():
+    from vsrlab_amd.core.utils import resize
+    from vsrlab_amd.optim import FusedAdam
+    with pytest.raises(RuntimeError):
+        FusedAdam([torch.nn.Parameter(torch.zeros(4))])
+    with pytest.raises(RuntimeError):
+        resize(torch.zeros(1, 3, 8, 8), (2, 2))

@@ -45,6 +45,11 @@ _SIGNATURES = {
     "vsr_conv3x3_c64_wgrad_slab_floats": (c_size_t, []),
     "vsr_conv3x3_c64_wgrad": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vsr_charbonnier_fwd_bwd": (c_int, [_P, _P, _P, _P, c_longlong, c_float, _P]),
+    "vsr_optim_scratch_floats": (c_size_t, []),
+    "vsr_adam_clip_step": (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int, c_float,
+                                   c_float, _P, _P, _P]),
+    "vsr_grad_norm": (c_int, [_P, c_longlong, c_float, _P, _P, _P]),
+    "vsr_resize_bilinear": (c_int, [_P, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -268,6 +268,16 @@ def spynet_flow(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.T
 # --------------------------------------------------------------------------------------------- #
 # whole BasicVSR path (reference: modules/basicvsr.py:39-83 + autograd)
 # --------------------------------------------------------------------------------------------- #
+def _under_ddp() -> bool:
+    """True while a torch DistributedDataParallel wrapper is running this forward (DDP's own class-level
+    ``_active_ddp_module`` marker, set for the duration of its forward)."""
+    try:
+        from torch.nn.parallel import DistributedDataParallel
+        return getattr(DistributedDataParallel, "_active_ddp_module", None) is not None
+    except Exception:
+        return False
+
+
 class Workspace:
     """One arena per in-flight forward.  A forward that needs a backward keeps its arena until
     that backward has run (or its graph was dropped)."""
@@ -303,7 +313,7 @@ class _CtxToken:
 
 class _BasicVSRFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lrs, desc_tuple, pool, n_trainable, need_bwd, *params):
+    def forward(ctx, lrs, desc_tuple, pool, n_trainable, need_bwd, direct, *params):
         n, t, h, w, mid, rb, up, dtype = desc_tuple
         desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
         lib = _lib.load()
@@ -326,36 +336,70 @@ class _BasicVSRFn(torch.autograd.Function):
         ctx.need_bwd = need_bwd
         ctx.lr32 = lr32
         ctx.ps = ps
+        ctx.direct = direct
+        ctx.params = params                 # the leaves themselves: their .grad is re-attached to the arena slot
+        ctx.consumed = False
         return sr
 
     @staticmethod
     def backward(ctx, dsr):
         if not ctx.need_bwd:
             raise RuntimeError("vsrlab_amd: backward through a forward that ran without need_backward")
+        if ctx.consumed:
+            # the arena went back to the pool after the first backward (a later forward of the same shape may have
+            # overwritten the saved activations): fail like PyTorch does for freed buffers instead of returning garbage
+            raise RuntimeError("vsrlab_amd: trying to backward through the BasicVSR graph a second time: the saved "
+                               "activations live in a pooled workspace that was released by the first backward")
         n, t, h, w, mid, rb, up, dtype = ctx.desc_tuple
         desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
         lib = _lib.load()
         ps = ctx.ps
-        # need_bwd == 2 (train_flow): the SPyNet conv weights / biases (everything but the trailing mean, std buffers)
-        # are differentiated too
+        # need_bwd == 2 (train_flow / input gradient): the SPyNet conv weights / biases (everything but the trailing mean,
+        # std buffers) may be differentiated too
         n_diff = len(ps) - 2 if ctx.need_bwd == 2 else ctx.n_trainable
-        # one zero-filled arena for all gradients (a fill kernel per tensor costs ~1 ms per step at 254 tensors);
-        # the engine produces weight and bias gradients together, so every differentiated tensor gets a slot
-        sizes = [p.numel() if k < n_diff else 0 for k, p in enumerate(ps)]
+        # Tensors come in (weight, bias) pairs and the engine produces a pair's gradients together: a pair gets slots iff
+        # one of its members needs a gradient; everything else is NULL (e.g. all of a frozen SPyNet when only the input
+        # clip is differentiated: no 7x7 weight gradient is computed at all).
+        need = [k < n_diff and bool(ctx.needs_input_grad[6 + k]) for k in range(len(ps))]
+        want = [k < n_diff and (need[k & ~1] or need[k | 1]) for k in range(len(ps))]
+        # Gradient destinations.  A parameter managed by vsrlab_amd.optim.FusedAdam carries `_vsr_grad_slot`, a view of
+        # the optimizer's flat gradient arena: the engine accumulates (+=) straight into it -- what autograd's
+        # AccumulateGrad would do -- and autograd gets None for it.  Everything else goes through ONE zero-filled
+        # scratch arena (a fill kernel per tensor costs ~1 ms per step at 254 tensors) and is returned to autograd.
+        direct = ctx.direct if ctx.direct is not None else [None] * len(ps)
+        sizes = [ps[k].numel() if (want[k] and direct[k] is None) else 0 for k in range(len(ps))]
         offs = [0]
         for sz in sizes:
             offs.append(offs[-1] + ((sz + 63) // 64) * 64)          # 256-byte aligned slots
-        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dsr.device)
-        want_all = [flat[offs[k]:offs[k] + sizes[k]].view(p.shape) if k < n_diff else None for k, p in enumerate(ps)]
-        grads: List[Optional[torch.Tensor]] = [
-            want_all[k] if (k < n_diff and ctx.needs_input_grad[5 + k]) else None for k in range(len(ps))]
+        flat = torch.zeros(max(offs[-1], 1), dtype=torch.float32, device=dsr.device)
+        dest: List[Optional[torch.Tensor]] = []
+        for k, p in enumerate(ps):
+            if not want[k]:
+                dest.append(None)
+            elif direct[k] is not None:
+                dest.append(direct[k])
+            else:
+                dest.append(flat[offs[k]:offs[k] + sizes[k]].view(p.shape))
         dlrs = torch.empty_like(ctx.lr32) if ctx.needs_input_grad[0] else None      # gradient w.r.t. the clip (need_bwd == 2)
-        _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(want_all), len(ps), _ptr(ctx.lr32),
+        _lib.check(lib.vsr_basicvsr_backward(ctypes.byref(desc), _ptr_array(ps), _ptr_array(dest), len(ps), _ptr(ctx.lr32),
                                              _ptr(_f32c(dsr)), _ptr(dlrs), _ptr(ctx.ws.buf), ctx.ws.buf.numel(), _stream()),
                    "basicvsr_backward")
+        ctx.consumed = True
         ctx.ws.owner = None
         ctx.token = None
-        return (dlrs, None, None, None, None) + tuple(grads)
+        grads: List[Optional[torch.Tensor]] = []
+        for k in range(len(ps)):
+            if not need[k]:
+                grads.append(None)
+            elif direct[k] is not None:
+                leaf = ctx.params[k]
+                if leaf.grad is None or leaf.grad.data_ptr() != direct[k].data_ptr():
+                    leaf.grad = direct[k]                            # e.g. after zero_grad(set_to_none=True)
+                grads.append(None)
+            else:
+                grads.append(dest[k])
+        ctx.params = None
+        return (dlrs, None, None, None, None, None) + tuple(grads)
 
 
 def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_trainable: int, mid_channels: int,
@@ -376,7 +420,12 @@ def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_traina
             need_bwd = 2                                      # input-clip and / or SPyNet gradients: SPyNet's activations are kept
         elif any(p.requires_grad for p in params[:n_trainable]):
             need_bwd = 1
-    return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, need_bwd, *params)
+    # parameters owned by vsrlab_amd.optim.FusedAdam receive their gradient in place (see _BasicVSRFn.backward);
+    # under DistributedDataParallel the gradients must flow through autograd so that DDP's hooks fire
+    direct = [getattr(p, "_vsr_grad_slot", None) if (p.requires_grad and not _under_ddp()) else None for p in params]
+    if not any(d is not None for d in direct):
+        direct = None
+    return _BasicVSRFn.apply(lrs, desc_tuple, pool, n_trainable, need_bwd, direct, *params)
 
 
 def basicvsr_flows(lrs_shape, mid_channels, res_blocks, upscale, ws: Workspace, dtype: int, device):
