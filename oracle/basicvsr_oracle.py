@@ -141,6 +141,8 @@ def keyed_tensor(key: str, shape: Tuple[int, ...]) -> Tensor:
     v = torch.randn(shape, generator=g, dtype=torch.float32)
     if key.endswith("bias"):
         return v * 0.01
+    if key.endswith(("weight_u", "weight_v")):          # spectral_norm's power-iteration vectors: unit norm
+        return v / v.norm()
     fan_in = shape[1] * shape[2] * shape[3]
     # 0.7/sqrt(fan_in) keeps a 30-block trunk O(1); the SPyNet convs get a larger gain so
     # that the synthetic flows reach a few pixels and the warps are genuinely exercised

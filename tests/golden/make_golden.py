@@ -232,8 +232,98 @@ def realtrain():
     print("realbasicvsr_m64_train_autocast", {k: v.shape for k, v in out.items()})
 
 
+def disc():
+    """UNetDiscriminator (unet-discriminator.py:4-31, SpectralConv core/modules/conv.py:6-13) and the losses of one GAN
+    iteration with perceptual_loss = null (train_gan.py:35-58, core/losses.py:66-74, core/utils.py:235-240).  The module
+    name has a hyphen, so it is imported the way Hydra does it (importlib.import_module, core/utils.py:138).  fp64
+    reference, training mode (one power iteration per forward).  `kornia` is not installed: compute_loss's
+    `resize` is kornia's documented default (bilinear, align_corners=False, no antialias) = F.interpolate, restated in
+    the generating code below -- that one call is therefore pinned by torch, not by the reference ("parity unpinned"
+    for the choice of kornia defaults)."""
+    import importlib
+    torch.set_num_threads(8)
+    import_reference()
+    mod = importlib.import_module("vsrlab.vsr.models.RealBasicVSR.modules.unet-discriminator")
+    from oracle.basicvsr_oracle import keyed_tensor
+    d = mod.UNetDiscriminator(3, 64)
+    sd = {k: keyed_tensor(k, tuple(v.shape)) for k, v in d.state_dict().items()}
+    d.load_state_dict(sd, strict=True)
+    d = d.double().train()
+    keys = sorted(d.state_dict().keys())
+    img = rand(41, 2, 3, 32, 48).double().requires_grad_(True)
+    cot = rand(42, 2, 1, 32, 48, lo=-1, hi=1).double()
+    out = d(img)
+    torch.mean(out * cot).backward()
+    named = dict(d.named_parameters())
+    store = {"seed_img": np.asarray(41), "seed_cot": np.asarray(42), "out": out.detach().float().numpy(),
+             "dimg": img.grad.detach().float().numpy(), "keys": np.asarray(keys)}
+    for k, p in named.items():
+        g = p.grad.detach()
+        tag = k.replace(".", "__")
+        if g.numel() <= 40000:
+            store["grad__" + tag] = g.float().numpy()
+        store["gsum__" + tag] = np.asarray(float(g.sum()))
+        store["gnorm__" + tag] = np.asarray(float(g.norm()))
+        store["gproj__" + tag] = np.asarray(float((g * proj_vector(k, tuple(g.shape))).sum()))
+    for k, v in d.state_dict().items():                      # buffers after the training-mode forward
+        if k.endswith(("weight_u", "weight_v")):
+            store["buf__" + k.replace(".", "__")] = v.detach().float().numpy()
+    np.savez_compressed(os.path.join(HERE, "unet_discriminator.npz"), **store)
+    print("unet_discriminator", len(store))
+
+    # one GAN iteration's two losses and their gradients w.r.t. sr / lq (generator side) and D's parameters
+    from vsrlab.core.modules import conv  # noqa: F401
+    import torch.nn.functional as F
+
+    class Adv(nn.Module):                                     # core/losses.py:66-74 (losses.py itself imports kornia / torchvision)
+        def __init__(self, weight=2e-5):
+            super().__init__()
+            self.weight = weight
+
+        def forward(self, x, target, is_disc=False):
+            target = x.new_ones(x.size()) * target
+            loss = F.binary_cross_entropy_with_logits(x, target)
+            return loss if is_disc else loss * self.weight
+
+    def charb(x, y, eps=1e-9):                                # core/losses.py:15-18
+        diff = x - y
+        return torch.mean(torch.sqrt((diff * diff) + eps))
+
+    d.load_state_dict(sd, strict=True)
+    d = d.double().train()
+    adv = Adv()
+    b, t, c, h, w = 1, 2, 3, 32, 48
+    sr = rand(43, b, t, c, h, w).double().requires_grad_(True)
+    hr = rand(44, b, t, c, h, w).double()
+    lq = rand(45, b, t, c, h // 4, w // 4).double().requires_grad_(True)
+    tgt = F.interpolate(hr.reshape(-1, c, h, w), size=(h // 4, w // 4), mode="bilinear", align_corners=False).reshape(b, t, c, h // 4, w // 4)
+    pixel = charb(sr, hr) + charb(lq, tgt)                    # compute_loss, core/utils.py:235-240
+    disc_sr = d(sr.reshape(-1, c, h, w))                      # generator_step, train_gan.py:35-48
+    loss_g = pixel + 0.0 + adv(disc_sr, 1, False)
+    loss_g.backward()
+    g_sr, g_lq = sr.grad.detach().clone(), lq.grad.detach().clone()
+    d.zero_grad()
+    loss_d = adv(d(hr.reshape(-1, c, h, w)), 1, True) + adv(d(sr.detach().reshape(-1, c, h, w)), 0, True)   # train_gan.py:50-58
+    loss_d.backward()
+    store = {"seed_sr": np.asarray(43), "seed_hr": np.asarray(44), "seed_lq": np.asarray(45), "loss_g": np.asarray(float(loss_g)),
+             "loss_d": np.asarray(float(loss_d)), "dsr": g_sr.float().numpy(), "dlq": g_lq.float().numpy()}
+    for k, p in dict(d.named_parameters()).items():
+        g = p.grad.detach()
+        tag = k.replace(".", "__")
+        store["gsum__" + tag] = np.asarray(float(g.sum()))
+        store["gnorm__" + tag] = np.asarray(float(g.norm()))
+        store["gproj__" + tag] = np.asarray(float((g * proj_vector(k, tuple(g.shape))).sum()))
+    for k, v in d.state_dict().items():
+        if k.endswith(("weight_u", "weight_v")):
+            store["buf__" + k.replace(".", "__")] = v.detach().float().numpy()
+    np.savez_compressed(os.path.join(HERE, "gan_step.npz"), **store)
+    print("gan_step", len(store))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "disc"):
+        disc()
     if which in ("all", "realtrain"):
         realtrain()
     if which in ("all", "main"):

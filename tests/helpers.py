@@ -14,7 +14,7 @@ def rand(seed, *shape, lo=0.0, hi=1.0):
 
 def golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
-        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files if z[k].dtype.kind in "fiub"}   # string arrays (key lists) are read by the tests that need them
 
 
 def rel_err(a, b):

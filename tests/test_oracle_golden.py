@@ -1,6 +1,9 @@
 """CPU: the oracle restatement vs. golden vectors produced by the real reference
 (tests/golden/make_golden.py).  Tolerance: 1e-5 relative (both sides are fp32 ATen on CPU;
 the only differences are summation order inside the restated flow_warp)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -170,3 +173,67 @@ def test_realbasicvsr_forward_64_channels():
         sr, lq = O.realbasicvsr_forward(sd, lrs)
     assert rel_err(lq, g["lq"]) < TOL
     assert rel_err(sr, g["sr"]) < TOL
+
+
+# ---- GAN side (BASELINE config 3): UNetDiscriminator + SpectralConv + the two losses of one GAN iteration ----
+def _proj(key, shape):
+    from helpers import proj_vector
+    return proj_vector(key, shape)
+
+
+def test_unet_discriminator_forward_backward_and_buffers():
+    """oracle/discriminator_oracle.py against the reference's own fp64 run (tests/golden/make_golden.py `disc`):
+    logits, d/d img, every parameter gradient (small ones in full, all by sum / norm / seeded projection) and the
+    spectral-norm buffers after the training-mode forward."""
+    from oracle import discriminator_oracle as D
+    g = golden("unet_discriminator")
+    shapes = D.disc_param_shapes(3, 64)
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_discriminator.npz"), allow_pickle=False) as z:
+        assert sorted(shapes) == [str(k) for k in z["keys"]]          # state_dict keys of the reference module
+    sd = {k: v.double() for k, v in O.keyed_state_dict(shapes).items()}
+    leaves = {k: v.clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in sd.items()}
+    img = rand(int(g["seed_img"]), 2, 3, 32, 48).double().requires_grad_(True)
+    cot = rand(int(g["seed_cot"]), 2, 1, 32, 48, lo=-1, hi=1).double()
+    nb = {}
+    out = D.discriminator_forward(leaves, img, True, nb)
+    torch.mean(out * cot).backward()
+    assert rel_err(out, g["out"]) < 1e-6
+    assert rel_err(img.grad, g["dimg"]) < 1e-6
+    n = 0
+    for k, v in leaves.items():
+        if not v.requires_grad:
+            assert rel_err(nb[k], g["buf__" + k.replace(".", "__")]) < 1e-6, k
+            continue
+        tag = k.replace(".", "__")
+        gr = v.grad
+        if "grad__" + tag in g:
+            assert rel_err(gr, g["grad__" + tag]) < 1e-6, k
+        assert abs(float(gr.norm()) - float(g["gnorm__" + tag])) < 1e-6 * float(g["gnorm__" + tag]), k
+        assert abs(float((gr * _proj(k, tuple(gr.shape))).sum()) - float(g["gproj__" + tag])) < 1e-6 * float(g["gnorm__" + tag]) * gr.numel() ** 0.5, k
+        n += 1
+    assert n == 12
+
+
+def test_gan_iteration_losses_and_gradients():
+    """generator / discriminator losses of one GAN iteration (train_gan.py:35-58 with perceptual_loss null) and their
+    gradients w.r.t. sr, lq and D's parameters, against the reference-generated golden."""
+    from oracle import discriminator_oracle as D
+    g = golden("gan_step")
+    sd = {k: v.double() for k, v in O.keyed_state_dict(D.disc_param_shapes(3, 64)).items()}
+    b, t, c, h, w = 1, 2, 3, 32, 48
+    sr = rand(int(g["seed_sr"]), b, t, c, h, w).double().requires_grad_(True)
+    hr = rand(int(g["seed_hr"]), b, t, c, h, w).double()
+    lq = rand(int(g["seed_lq"]), b, t, c, h // 4, w // 4).double().requires_grad_(True)
+    leaves = {k: v.clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in sd.items()}
+    loss_g, loss_d, bufs = D.gan_losses(leaves, sr, hr, lq)
+    assert abs(float(loss_g) - float(g["loss_g"])) < 1e-9 and abs(float(loss_d) - float(g["loss_d"])) < 1e-9
+    gs, gl = torch.autograd.grad(loss_g, [sr, lq], retain_graph=True)
+    assert rel_err(gs, g["dsr"]) < 1e-6 and rel_err(gl, g["dlq"]) < 1e-6
+    train = [k for k, v in leaves.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss_d, [leaves[k] for k in train])
+    for k, gr in zip(train, grads):
+        tag = k.replace(".", "__")
+        assert abs(float(gr.norm()) - float(g["gnorm__" + tag])) < 1e-6 * float(g["gnorm__" + tag]), k
+        assert abs(float((gr * _proj(k, tuple(gr.shape))).sum()) - float(g["gproj__" + tag])) < 1e-6 * float(g["gnorm__" + tag]) * gr.numel() ** 0.5, k
+    for k, v in bufs.items():                                  # u / v after the three training-mode forwards
+        assert rel_err(v, g["buf__" + k.replace(".", "__")]) < 1e-6, k
