@@ -183,6 +183,35 @@ int vsr_grad_norm(const float* grads, long long numel, float grad_scale, float* 
  * resize(hr, (h, w)) in compute_loss (core/utils.py:235-240), the target of the pre-clean stack's loss term.  */
 int vsr_resize_bilinear(const float* in, float* out, long long planes, int H, int W, int h, int w, void* stream);
 
+/* ---- GAN side of RealBasicVSR training (BASELINE config 3; csrc/conv_wide.hip, csrc/disc_engine.hip) -------------
+ * UNetDiscriminator.forward and its backward (vsr/models/RealBasicVSR/modules/unet-discriminator.py:4-31) on a batch of
+ * frames img (n,3,h,w) fp32 planar, h and w multiples of 8 -> logits out (n,1,h,w) fp32 planar.  mid_ch must be 64.
+ * params: 12 device pointers, fp32 OIHW, in module order: conv_0.weight, conv_0.bias, the EFFECTIVE weights of conv_1 ..
+ * conv_8 (= weight_orig / sigma, see vsr_spectral_norm; SpectralConv has no bias, core/modules/conv.py:6-13),
+ * conv_9.weight, conv_9.bias.                                                                                     */
+typedef struct VsrDiscDesc { int n, h, w, mid_ch, dtype; } VsrDiscDesc;
+size_t vsr_disc_workspace_bytes(const VsrDiscDesc* d, int need_backward);
+int vsr_disc_forward(const VsrDiscDesc* d, const float* const* params, int nparams, const float* img, float* out,
+                     void* workspace, size_t workspace_bytes, int need_backward, void* stream);
+/* Back-propagates dout (n,1,h,w) through the forward that last ran on `workspace` (need_backward = 1).  grads[k]
+ * (layout of params; NULL = not wanted, a bias needs its weight's entry) are ACCUMULATED into; dimg (n,3,h,w) or NULL is
+ * written (the generator's adversarial gradient, train_gan.py:35-48).                                              */
+int vsr_disc_backward(const VsrDiscDesc* d, float* const* grads, int nparams, const float* img, const float* dout,
+                      float* dimg, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.nn.utils.spectral_norm's compute_weight (n_power_iterations = 1, eps 1e-12) for one SpectralConv
+ * (core/modules/conv.py:9): w_orig viewed as (rows = cout, cols = cin*kh*kw).  training != 0: u and v are UPDATED in
+ * place by one power iteration first (v = normalize(W^T u), u = normalize(W v)); then sigma[0] = u.(W v) and
+ * w_out = w_orig / sigma.  rows <= 512.                                                                            */
+int vsr_spectral_norm(const float* w_orig, float* u, float* v, float* w_out, float* sigma, int rows, int cols,
+                      int training, void* stream);
+/* dw_orig += dw / sigma - (sum(dw * w_orig) / sigma^2) u v^T   (u, v are constants of the graph, as in torch)        */
+int vsr_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v, const float* sigma,
+                               float* dw_orig, int rows, int cols, void* stream);
+
+/* AdversarialLoss's core (core/losses.py:66-74): loss[0] = mean BCE-with-logits(x, target); dx (optional) = its gradient */
+int vsr_bce_with_logits(const float* x, float target, float* dx, float* loss, long long numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

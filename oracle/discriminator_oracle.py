@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from .basicvsr_oracle import charbonnier
+from .basicvsr_oracle import _gq, _iq, _q, _wq, charbonnier     # emulate_bf16() rounding points (no-ops by default)
 
 
 def disc_param_shapes(in_ch: int = 3, mid_ch: int = 64) -> Dict[str, Tuple[int, ...]]:
@@ -59,19 +59,21 @@ def discriminator_forward(sd: Mapping[str, Tensor], img: Tensor, training: bool 
         w, u, v, _ = spectral_normalize(sd[pre + "weight_orig"], sd[pre + "weight_u"], sd[pre + "weight_v"], training)
         if new_buffers is not None:
             new_buffers[pre + "weight_u"], new_buffers[pre + "weight_v"] = u.detach(), v.detach()
-        return F.conv2d(x, w, None, stride, pad)
+        return F.conv2d(x, _wq(w), None, stride, pad)
 
-    f0 = lrelu(F.conv2d(img, sd["conv_0.weight"], sd["conv_0.bias"], 1, 1))
-    f1 = lrelu(sconv(1, f0, 2, 1))
-    f2 = lrelu(sconv(2, f1, 2, 1))
-    f3 = lrelu(sconv(3, f2, 2, 1))
-    f3 = up(f3)
-    f4 = up(lrelu(sconv(4, f3, 1, 1)) + f2)
-    f5 = up(lrelu(sconv(5, f4, 1, 1)) + f1)
-    f6 = lrelu(sconv(6, f5, 1, 1)) + f0
-    out = lrelu(sconv(7, f6, 1, 1))
-    out = lrelu(sconv(8, out, 1, 1))
-    return F.conv2d(out, sd["conv_9.weight"], sd["conv_9.bias"], 1, 1)
+    # _q / _wq / _iq / _gq: identity unless basicvsr_oracle.emulate_bf16() is active; then they round where the HIP bf16
+    # build stores a tensor (every activation written to HBM, the packed weights, the image staged into conv_0)
+    f0 = _q(lrelu(F.conv2d(_iq(img), _wq(sd["conv_0.weight"]), sd["conv_0.bias"], 1, 1)))
+    f1 = _q(lrelu(sconv(1, f0, 2, 1)))
+    f2 = _q(lrelu(sconv(2, f1, 2, 1)))
+    f3 = _q(lrelu(sconv(3, f2, 2, 1)))
+    f3 = _q(up(f3))
+    f4 = _q(up(_q(lrelu(sconv(4, f3, 1, 1))) + f2))
+    f5 = _q(up(_q(lrelu(sconv(5, f4, 1, 1))) + f1))
+    f6 = _q(_q(lrelu(sconv(6, f5, 1, 1))) + f0)
+    out = _q(lrelu(sconv(7, f6, 1, 1)))
+    out = _q(lrelu(sconv(8, out, 1, 1)))
+    return _gq(F.conv2d(out, _wq(sd["conv_9.weight"]), sd["conv_9.bias"], 1, 1))
 
 
 def adversarial_loss(x: Tensor, target: float, is_disc: bool = False, weight: float = 2e-5) -> Tensor:

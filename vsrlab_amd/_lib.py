@@ -20,6 +20,11 @@ class BasicVSRDesc(ctypes.Structure):
                 ("res_blocks", c_int), ("upscale", c_int), ("dtype", c_int)]
 
 
+class DiscDesc(ctypes.Structure):
+    """struct VsrDiscDesc (include/vsrlab_hip.h)."""
+    _fields_ = [("n", c_int), ("h", c_int), ("w", c_int), ("mid_ch", c_int), ("dtype", c_int)]
+
+
 _P = c_void_p
 _SIGNATURES = {
     "vsr_abi_version": (c_int, []),
@@ -50,6 +55,12 @@ _SIGNATURES = {
                                    c_float, _P, _P, _P]),
     "vsr_grad_norm": (c_int, [_P, c_longlong, c_float, _P, _P, _P]),
     "vsr_resize_bilinear": (c_int, [_P, _P, c_longlong, c_int, c_int, c_int, c_int, _P]),
+    "vsr_disc_workspace_bytes": (c_size_t, [ctypes.POINTER(DiscDesc), c_int]),
+    "vsr_disc_forward": (c_int, [ctypes.POINTER(DiscDesc), _P, c_int, _P, _P, _P, c_size_t, c_int, _P]),
+    "vsr_disc_backward": (c_int, [ctypes.POINTER(DiscDesc), _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "vsr_spectral_norm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vsr_spectral_norm_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "vsr_bce_with_logits": (c_int, [_P, c_float, _P, _P, c_longlong, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -3,9 +3,41 @@
 arguments, same parameter names (``conv.0.weight``, ``res_block.{i}.conv1.weight`` ...), so
 checkpoints load strictly.  The modules are parameter containers: inside ``BasicVSR`` the whole
 propagation runs in one engine call; called on their own they dispatch to the per-op kernels."""
+import torch
 import torch.nn as nn
 
 from ... import functional as VF
+
+
+class _SpectralConv2d(nn.Module):
+    """The parameters / buffers ``torch.nn.utils.spectral_norm(nn.Conv2d(..., bias=False))`` registers
+    (``weight_orig``, ``weight_u``, ``weight_v``: same names, shapes and initialisation), so reference checkpoints
+    load strictly.  The normalisation itself (one power iteration per training forward) runs in
+    ``vsr_spectral_norm`` inside the discriminator's HIP call."""
+
+    def __init__(self, in_ch, out_ch, ks, stride, pad):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_ch, out_ch, ks, stride, pad
+        conv = nn.Conv2d(in_ch, out_ch, ks, stride, pad, bias=False)          # for its default initialisation
+        self.weight_orig = nn.Parameter(conv.weight.detach().clone())
+        with torch.no_grad():
+            u = nn.functional.normalize(torch.randn(out_ch), dim=0, eps=1e-12)
+            v = nn.functional.normalize(torch.randn(in_ch * ks * ks), dim=0, eps=1e-12)
+        self.register_buffer("weight_u", u)
+        self.register_buffer("weight_v", v)
+
+
+class SpectralConv(nn.Module):
+    """spectral_norm(Conv2d(in_ch, out_ch, ks, stride, pad, bias=False))  (conv.py:6-13).  A building block of
+    ``UNetDiscriminator``, which runs all of its layers in one engine call."""
+
+    def __init__(self, in_ch, out_ch, ks=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = _SpectralConv2d(in_ch, out_ch, ks, stride, pad)
+
+    def forward(self, x):
+        raise NotImplementedError("SpectralConv runs inside the UNetDiscriminator engine (vsr_disc_forward); "
+                                  "standalone use is not on the HIP path")
 
 
 class ConvReLU(nn.Module):

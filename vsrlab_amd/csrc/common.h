@@ -75,7 +75,12 @@ struct ConvArgs {
     // ignore both and use `aux`.
     void* sign_out[VSR_MAX_Z];
     const void* sign_bits[VSR_MAX_Z];
+    // LeakyReLU slope of ACT_LEAKY / MASK_LEAKY: 0 = the path's 0.1 (basicvsr.py:18,21; conv.py:97); the discriminator
+    // uses 0.2 (unet-discriminator.py:19)
+    float leaky_slope;
+    int planar_c;                        // channels of a planar fp32 source (LASTPLANAR): 0 = 3
 };
+static inline __host__ __device__ float vsr_slope(float s) { return s != 0.f ? s : 0.1f; }
 
 // Weight-gradient launch: dW[z][tap][cout][cin] = sum_p dY[p][cout] * X[p + tap][cin] over up to
 // VSR_WG_MAXSEG (X, dY) segment pairs (the frames of a clip share one launch and one reduction).
@@ -90,7 +95,9 @@ struct WgradArgs {
     int dy_step, dy_oy, dy_ox, Hy, Wy; // dy view -> underlying image
     float* slab;                 // [gridDim.x][slab_stride] fp32 partials
     int tap_begin;               // first tap of this launch (7x7 kernels go one kernel row per launch)
-    int x_ctotal, x_coff;        // generic kernel: channels per pixel of the X tensor (0 = CX) and first 8-channel chunk used
+    int x_ctotal, x_coff;        // channels per pixel of the X tensor (0 = CX) and first 8-channel chunk used (64-channel slices of a wider tensor)
+    int dy_ctotal, dy_coff;      // the same for dY
+    int dy_planar_c;             // channels of a planar fp32 dY (DYPLANAR): 0 = 3
     int slab_stride;
     int ntiles_x, ntiles_y;
 };

@@ -41,9 +41,9 @@ constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11 
 
 __device__ uint4 g_conv_zero_chunk[2];
 
-template <int ACT> __device__ __forceinline__ float p_act(float v) {
+template <int ACT> __device__ __forceinline__ float p_act(float v, float slope) {
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (ACT == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+    if (ACT == ACT_LEAKY) return v > 0.f ? v : slope * v;
     return v;
 }
 
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         stage_weights();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // weights and the first tile are in LDS
+        const float slope = vsr_slope(a.leaky_slope);      // LeakyReLU slope (0.1 on the BasicVSR path, 0.2 in the discriminator)
 
         int cur = 0;
         for (int tile = walk.first; tile < walk.end; tile += walk.stride) {
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     for (int mb = 0; mb < 4; ++mb) {
                         float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = p_act<ACT>(acc[mb][nb][j]);
+                        for (int j = 0; j < 4; ++j) v[j] = p_act<ACT>(acc[mb][nb][j], slope);
                         if (HAS_RES) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += (float)rr[mb][nb].v[j];
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                             for (int j = 0; j < 4; ++j)     // sign-extended 1-bit field = all-ones / zero mask on the float's bits
                                 v[j] = __uint_as_float(__float_as_uint(v[j]) & (unsigned)__builtin_amdgcn_sbfe((int)wbits, (((mb * 4 + nb) & 7) * 4) + j, 1));
                         } else if (MASK != MASK_NONE) {
-                            constexpr float neg = MASK == MASK_LEAKY ? 0.1f : 0.f;
+                            const float neg = MASK == MASK_LEAKY ? slope : 0.f;
                             const bf4 mv = LATE_MASK ? *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[nb] + mb * 512)
                                                      : mm[mb][nb];
 #pragma unroll
@@ -402,6 +403,7 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     PERSIST_CASE(ACT_NONE, false, MASK_RELU)     // dgrad(conv2) * ReLU'
     PERSIST_CASE(ACT_NONE, false, MASK_RELU_BITS)   // the same, from the sign bits the bias+ReLU launch left (4 MB instead of 66 MB)
     PERSIST_CASE(ACT_NONE, true, MASK_LEAKY)     // (dgrad(conv1 of block 0) + dX) * LeakyReLU' of the stem
+    PERSIST_CASE(ACT_NONE, false, MASK_LEAKY)    // dgrad * LeakyReLU' (discriminator conv_7 / conv_8)
 #undef PERSIST_CASE
     return VSR_ERR_UNSUPPORTED;
 }

@@ -88,9 +88,9 @@ template <typename T> struct Vec4;
 template <> struct __attribute__((aligned(8))) Vec4<bf16_t> { bf16_t v[4]; };
 template <> struct __attribute__((aligned(16))) Vec4<float> { float v[4]; };
 
-__device__ __forceinline__ float act_apply(float v, int act) {
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+    if (act == ACT_LEAKY) return v > 0.f ? v : slope * v;
     return v;
 }
 
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
                     if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
                         const long long o = (long long)(vy * a.in_step + a.src_oy[s]) * a.Ws + (vx * a.in_step + a.src_ox[s]);
-                        c0 = base[o]; c1 = base[o + plane]; c2 = base[o + 2 * plane];
+                        const int pc = a.planar_c ? a.planar_c : 3;
+                        c0 = base[o]; c1 = pc > 1 ? base[o + plane] : 0.f; c2 = pc > 2 ? base[o + 2 * plane] : 0.f;
                     }
                     *reinterpret_cast<chunk_t*>(lds_in + (p * 2 + swz<2>(p, 0)) * CHB) = make_chunk3(c0, c1, c2, (T*)nullptr);
                     *reinterpret_cast<chunk_t*>(lds_in + (p * 2 + swz<2>(p, 1)) * CHB) = zero_chunk<T>();
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], a.act);
+                    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], a.act, vsr_slope(a.leaky_slope));
                     if (res) {
                         const Vec4<T> r = *reinterpret_cast<const Vec4<T>*>(res + (co >> 3) * 256 + (co & 7));
 #pragma unroll
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                     }
                     if (aux) {
                         const Vec4<T> m = *reinterpret_cast<const Vec4<T>*>(aux + (co >> 3) * 256 + (co & 7));
-                        const float neg = a.mask_mode == MASK_LEAKY ? 0.1f : 0.f;
+                        const float neg = a.mask_mode == MASK_LEAKY ? vsr_slope(a.leaky_slope) : 0.f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= (to_f(m.v[j]) > 0.f ? 1.f : neg);
                     }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                     if (c >= a.cout_real) break;
                     float v = acc[0][rw][c];
                     if (a.bias) v += a.bias[(long long)z * a.bias_zstride + c];
-                    v = act_apply(v, a.act);
+                    v = act_apply(v, a.act, vsr_slope(a.leaky_slope));
                     if (a.pres) v += a.pres[(long long)n * a.dst_nstride + c * plane + (long long)oy * a.Wd + ox];
                     if (a.base_lr) {
                         const float* bp = a.base_lr + (long long)n * a.base_nstride + (long long)c * a.base_h * a.base_w;

@@ -1,0 +1,651 @@
+// Kernels of the GAN side of RealBasicVSR training (BASELINE config 3):
+//   UNetDiscriminator (vsr/models/RealBasicVSR/modules/unet-discriminator.py:4-31): 3x3 stride-1 convs at 128..512 channels,
+//   4x4 stride-2 convs, bilinear x2 upsampling between the U-Net levels, LeakyReLU(0.2);
+//   SpectralConv (core/modules/conv.py:6-13): torch.nn.utils.spectral_norm around every inner conv;
+//   AdversarialLoss (core/losses.py:66-74): BCE-with-logits against a constant target.
+//
+// "Wide" convolution = the implicit GEMM of conv_mfma.hip generalised in the channel direction: the input is a blocked
+// pixel-major tensor with 64 k channels, consumed as k SLICES of 64 (one haloed 10x34x64 tile in LDS at a time, the 64x64
+// weight slab of each (slice, tap) streamed through a double buffer); the output's 64 m channels are m independent
+// workgroup columns (blockIdx.z).  A 4x4 stride-2 convolution (pad 1) is the sum of four 2x2-tap convolutions on the
+// four PARITY VIEWS of its input (view_p(y, x) = in(2y + p_y, 2x + p_x)):
+//     out(y) = sum_ky W[ky] in(2y + ky - 1):  ky odd  -> view 0 at y + dy, dy = (ky - 1) / 2 in {0, 1}
+//                                             ky even -> view 1 at y + dy, dy = ky / 2 - 1   in {-1, 0}
+// and its data gradient writes the four OUTPUT PHASES of a twice-as-large image, each a 2x2-tap convolution of dY:
+//     dX(2q + p) = sum_ky W[ky] dY(q + dy):   p = 0 -> (dy 0, ky 1), (dy -1, ky 3);   p = 1 -> (dy +1, ky 0), (dy 0, ky 2)
+// so both run on the SAME 3x3-tap kernel with a per-view / per-phase tap mask (masked taps are skipped: no wasted MFMAs).
+// Everything here serves config 3, not the headline metric: it is built for correctness first, on the generic
+// 256-thread tile structure (two workgroups per CU), not tuned like conv3x3_persist.hip.
+#include <cmath>
+#include "kernels.h"
+#include "../../include/vsrlab_hip.h"
+
+namespace {
+
+constexpr int TW = 32, RW = 2, TH = 8, NTHREADS = 256;
+constexpr int TWH = TW + 2, THH = TH + 2, NPIX = THH * TWH;
+
+template <typename T> struct WE;
+template <> struct WE<bf16_t> { static constexpr int CHB = 16; typedef bf16x8_t frag_t; typedef uint4 chunk_t; };
+struct wf32x8_t { float v[8]; };
+struct wchunk_t { uint4 a, b; };
+template <> struct WE<float> { static constexpr int CHB = 32; typedef wf32x8_t frag_t; typedef wchunk_t chunk_t; };
+
+__device__ __forceinline__ void wmma(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void wmma(f32x16_t& acc, const wf32x8_t& a, const wf32x8_t& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ int wswz(int p, int c) { return c ^ ((p >> 1) & 7); }     // 8 chunks per 64-channel row
+template <typename T> __device__ __forceinline__ typename WE<T>::chunk_t wzero();
+template <> __device__ __forceinline__ uint4 wzero<bf16_t>() { return make_uint4(0, 0, 0, 0); }
+template <> __device__ __forceinline__ wchunk_t wzero<float>() { wchunk_t z; z.a = make_uint4(0, 0, 0, 0); z.b = z.a; return z; }
+__device__ __forceinline__ float wf(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float wf(float v) { return v; }
+template <typename T> struct WV4;
+template <> struct __attribute__((aligned(8))) WV4<bf16_t> { bf16_t v[4]; };
+template <> struct __attribute__((aligned(16))) WV4<float> { float v[4]; };
+
+struct WideArgs {
+    const void* x; long long x_nstride; int xC, Hx, Wx;   // source: blocked pixel-major, xC channels per pixel
+    int in_step;                                           // 2: the conv reads the four parity views of x
+    int nsl;                                               // 64-channel slices of x that are reduced over
+    int N, H, W;                                           // conv domain = output VIEW size
+    const void* wpack;                                     // [ophase][cob][source][9][64][64] of T
+    const float* bias;                                     // [ncob * 64] or null
+    void* y; long long y_nstride; int yC, Hy, Wy;          // destination image (blocked pixel-major, yC channels)
+    int out_step;                                          // 2: four output phases (transposed stride-2 conv)
+    int ncob;
+    unsigned tapmask[4];
+    int act; float slope;
+    void* y_act;                                           // optional: act(acc + bias), before the residual
+    const void* res;                                       // optional residual (destination layout)
+    void* y_pre;                                           // optional: value before the mask
+    const void* aux;                                       // optional mask source: aux > 0 ? 1 : slope
+};
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void conv_wide_kernel(const WideArgs a) {
+    constexpr int CHB = WE<T>::CHB;
+    constexpr int TILE_BYTES = NPIX * 8 * CHB;
+    constexpr int SLAB_BYTES = 64 * 8 * CHB;
+    typedef typename WE<T>::chunk_t chunk_t;
+    typedef typename WE<T>::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_in = smem;
+    char* lds_w = smem + TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int nph = a.out_step == 2 ? 4 : 1;
+    int zz = blockIdx.z;
+    const int cob = zz % a.ncob; zz /= a.ncob;
+    const int oph = zz % nph;
+    const int n = zz / nph;
+    const int nsrc = a.nsl * (a.in_step == 2 ? 4 : 1);
+    const int xCP = a.xC >> 3;
+
+    f32x16_t acc[2][RW];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][rw][i] = 0.f;
+
+    const T* wbase = reinterpret_cast<const T*>(a.wpack) + ((long long)(oph * a.ncob + cob) * nsrc) * 9 * 4096;
+    const T* xb = reinterpret_cast<const T*>(a.x) + (long long)n * a.x_nstride;
+    const int xws = pm_ws(a.Wx);
+
+    for (int s = 0; s < nsrc; ++s) {
+        const int slice = s % a.nsl, par = s / a.nsl;
+        const int oy = a.in_step == 2 ? (par >> 1) : 0, ox = a.in_step == 2 ? (par & 1) : 0;
+        const unsigned mask = a.tapmask[a.in_step == 2 ? par : oph];
+        __syncthreads();                                   // the previous source's tile and slabs are consumed
+        // ---- stage the haloed tile of this slice / view: [pixel][8 chunks], XOR-swizzled ----
+        for (int idx = tid; idx < NPIX * 8; idx += NTHREADS) {
+            const int p = idx >> 3, c = idx & 7;
+            const int ty = p / TWH, tx = p - ty * TWH;
+            const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+            chunk_t v = wzero<T>();
+            if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
+                const int sy = vy * a.in_step + oy, sx = vx * a.in_step + ox;
+                const long long o = (((long long)sy * xws + (sx >> 5)) * xCP + slice * 8 + c) * 256 + (sx & 31) * 8;
+                v = *reinterpret_cast<const chunk_t*>(xb + o);
+            }
+            *reinterpret_cast<chunk_t*>(lds_in + (p * 8 + wswz(p, c)) * CHB) = v;
+        }
+        const T* ws = wbase + (long long)s * 9 * 4096;
+        int buf = 0;
+        // first valid tap's slab
+        int tap = __builtin_ctz(mask | 0x200u);
+        chunk_t wreg[2];
+        if (tap < 9) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wreg[i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)tap * 512 + tid + i * NTHREADS) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * NTHREADS, r = idx >> 3, c = idx & 7;
+                *reinterpret_cast<chunk_t*>(lds_w + (r * 8 + wswz(r, c)) * CHB) = wreg[i];
+            }
+        }
+        __syncthreads();
+        while (tap < 9) {
+            const unsigned rest = (mask >> (tap + 1)) << (tap + 1);
+            const int next = __builtin_ctz(rest | 0x200u);
+            if (next < 9) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wreg[i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)next * 512 + tid + i * NTHREADS) * 8);
+            }
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const char* wbuf = lds_w + buf * SLAB_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = 2 * ks + h;
+                frag_t af[2], bf[RW];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int r = cb * 32 + l31;
+                    af[cb] = *reinterpret_cast<const frag_t*>(wbuf + (r * 8 + wswz(r, ch)) * CHB);
+                }
+#pragma unroll
+                for (int rw = 0; rw < RW; ++rw) {
+                    const int p = (wave * RW + rw + ky) * TWH + l31 + kx;
+                    bf[rw] = *reinterpret_cast<const frag_t*>(lds_in + (p * 8 + wswz(p, ch)) * CHB);
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int rw = 0; rw < RW; ++rw) wmma(acc[cb][rw], af[cb], bf[rw]);
+            }
+            if (next < 9) {
+                char* nbuf = lds_w + (buf ^ 1) * SLAB_BYTES;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = tid + i * NTHREADS, r = idx >> 3, c = idx & 7;
+                    *reinterpret_cast<chunk_t*>(nbuf + (r * 8 + wswz(r, c)) * CHB) = wreg[i];
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+            tap = next;
+        }
+    }
+
+    // ---- epilogue (accumulator layout: lane = pixel column, registers = 4-channel groups) ----
+    const int vx = tx0 + l31;
+    if (vx >= a.W) return;
+    const int yCP = a.yC >> 3;
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw) {
+        const int vy = ty0 + wave * RW + rw;
+        if (vy >= a.H) continue;
+        const int oyy = vy * a.out_step + (a.out_step == 2 ? (oph >> 1) : 0);
+        const int oxx = vx * a.out_step + (a.out_step == 2 ? (oph & 1) : 0);
+        const long long pix = (long long)n * a.y_nstride + (((long long)oyy * pm_ws(a.Wy) + (oxx >> 5)) * yCP + cob * 8) * 256 + (oxx & 31) * 8;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cb * 32 + 8 * g + 4 * h;
+                const long long o = pix + (co >> 3) * 256 + (co & 7);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[cb][rw][4 * g + j];
+                if (a.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(a.bias + cob * 64 + co);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (a.act == ACT_LEAKY) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : a.slope * v[j];
+                } else if (a.act == ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                }
+                WV4<T> t;
+                if (a.y_act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t.v[j] = (T)v[j];
+                    *reinterpret_cast<WV4<T>*>(reinterpret_cast<T*>(a.y_act) + o) = t;
+                }
+                if (a.res) {
+                    const WV4<T> r = *reinterpret_cast<const WV4<T>*>(reinterpret_cast<const T*>(a.res) + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += wf(r.v[j]);
+                }
+                if (a.y_pre) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t.v[j] = (T)v[j];
+                    *reinterpret_cast<WV4<T>*>(reinterpret_cast<T*>(a.y_pre) + o) = t;
+                }
+                if (a.aux) {
+                    const WV4<T> m = *reinterpret_cast<const WV4<T>*>(reinterpret_cast<const T*>(a.aux) + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= (wf(m.v[j]) > 0.f ? 1.f : a.slope);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t.v[j] = (T)v[j];
+                *reinterpret_cast<WV4<T>*>(reinterpret_cast<T*>(a.y) + o) = t;
+            }
+        }
+    }
+}
+
+// ---- weight packing for the wide kernel: OIHW fp32 (cout, cin, ks, ks) -> [ophase][cob][source][9][64 rows][64 cols] ----
+//   mode 0: forward, 3x3 stride 1      rows = cout block, cols = cin slice, tap = ky*3+kx
+//   mode 1: forward, 4x4 stride 2      sources = (parity view, cin slice); (view v, dy) -> ky = v ? 2*(dy+1) : 2*dy+1
+//   mode 2: data gradient of mode 0    rows = cin block, cols = cout slice, flipped taps
+//   mode 3: data gradient of mode 1    phases p: (dy, ky) in p = 0: {(0,1), (-1,3)}, p = 1: {(1,0), (0,2)}; rows = cin block
+__device__ __forceinline__ int s2_fwd_k(int view, int d) {             // d in {-1,0,1}; -1 = tap not used
+    if (view == 0) return d >= 0 ? 2 * d + 1 : -1;
+    return d <= 0 ? 2 * (d + 1) : -1;
+}
+__device__ __forceinline__ int s2_bwd_k(int phase, int d) {
+    if (phase == 0) return d == 0 ? 1 : (d == -1 ? 3 : -1);
+    return d == 1 ? 0 : (d == 0 ? 2 : -1);
+}
+template <typename T>
+__global__ void pack_wide_kernel(const float* __restrict__ w, T* __restrict__ dst, int cout, int cin, int mode, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx & 63), r = (int)((idx >> 6) & 63), tap = (int)((idx >> 12) % 9);
+    long long rest = (idx >> 12) / 9;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    float v = 0.f;
+    if (mode == 0) {
+        const int nsl = cin / 64;
+        const int slice = (int)(rest % nsl), cob = (int)(rest / nsl);
+        v = w[((long long)(cob * 64 + r) * cin + slice * 64 + c) * 9 + tap];
+    } else if (mode == 1) {
+        const int nsl = cin / 64;
+        const int slice = (int)(rest % nsl); rest /= nsl;
+        const int view = (int)(rest % 4), cob = (int)(rest / 4);
+        const int ky = s2_fwd_k(view >> 1, dy), kx = s2_fwd_k(view & 1, dx);
+        if (ky >= 0 && kx >= 0) v = w[((long long)(cob * 64 + r) * cin + slice * 64 + c) * 16 + ky * 4 + kx];
+    } else if (mode == 2) {
+        const int nsl = cout / 64;                          // the gradient reduces over the conv's OUTPUT channels
+        const int slice = (int)(rest % nsl), cob = (int)(rest / nsl);
+        v = w[((long long)(slice * 64 + c) * cin + cob * 64 + r) * 9 + (8 - tap)];
+    } else {
+        const int nsl = cout / 64, ncob = cin / 64;
+        const int slice = (int)(rest % nsl); rest /= nsl;
+        const int cob = (int)(rest % ncob), phase = (int)(rest / ncob);
+        const int ky = s2_bwd_k(phase >> 1, dy), kx = s2_bwd_k(phase & 1, dx);
+        if (ky >= 0 && kx >= 0) v = w[((long long)(slice * 64 + c) * cin + cob * 64 + r) * 16 + ky * 4 + kx];
+    }
+    dst[idx] = (T)v;
+}
+
+// Partial slabs of a 3x3 weight gradient taken on parity view `view` of a 4x4 stride-2 conv's input -> the 4x4 OIHW gradient
+// (accumulated): gw[co0 + co][ci0 + ci][ky][kx] += sum_wg slab[wg][tap][co][ci] for the 4 taps the view owns.
+__global__ void wgrad_reduce_s2_kernel(const float* __restrict__ slab, int nwg, int slab_stride, float* __restrict__ gw, int cin_total,
+                                       int co0, int ci0, int view) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 9 * 64 * 64) return;
+    const int ci = idx & 63, co = (idx >> 6) & 63, tap = idx >> 12;
+    const int ky = s2_fwd_k(view >> 1, tap / 3 - 1), kx = s2_fwd_k(view & 1, tap % 3 - 1);
+    if (ky < 0 || kx < 0) return;
+    float s = 0.f;
+    for (int wg = 0; wg < nwg; ++wg) s += slab[(long long)wg * slab_stride + idx];
+    gw[((long long)(co0 + co) * cin_total + ci0 + ci) * 16 + ky * 4 + kx] += s;
+}
+
+// ---- bilinear x2 (align_corners=False) on blocked pixel-major tensors, and its adjoint ----
+__device__ __forceinline__ void up2_src(int d, int in_size, int& i0, int& i1, float& l1) {
+    float s = ((float)d + 0.5f) * 0.5f - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* f);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float* f) {
+    union { uint4 u; bf16_t h[8]; } t; t.u = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)t.h[j];
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float* f) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* f);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float* f) {
+    union { uint4 u; bf16_t h[8]; } t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.h[j] = (bf16_t)f[j];
+    *reinterpret_cast<uint4*>(p) = t.u;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float* f) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// out (N, 2H, 2W, C) = up2(a [+ b]);  a, b: (N, H, W, C)
+template <typename T>
+__global__ void up2_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int N, int H, int W, int C) {
+    const int CP = C >> 3, H2 = 2 * H, W2 = 2 * W;
+    const long long total = (long long)N * H2 * W2 * CP;
+    const long long in_img = pm_image_elems(H, W, C), out_img = pm_image_elems(H2, W2, C);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CP);
+        const long long pix = idx / CP;
+        const int X = (int)(pix % W2), Y = (int)((pix / W2) % H2), n = (int)(pix / ((long long)W2 * H2));
+        int y0, y1, x0, x1; float ly, lx;
+        up2_src(Y, H, y0, y1, ly); up2_src(X, W, x0, x1, lx);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int yy = (t >> 1) ? y1 : y0, xx = (t & 1) ? x1 : x0;
+            const float wgt = ((t >> 1) ? ly : 1.f - ly) * ((t & 1) ? lx : 1.f - lx);
+            const long long o = (long long)n * in_img + pm_off(yy, xx, c, W, C);
+            float f[8];
+            ld8<T>(a + o, f);
+            if (b) { float g[8]; ld8<T>(b + o, g);
+#pragma unroll
+                     for (int j = 0; j < 8; ++j) f[j] += g[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
+        }
+        st8<T>(out + (long long)n * out_img + pm_off(Y, X, c, W2, C), acc);
+    }
+}
+
+// adjoint: din (N, H, W, C) = up2^T(dout (N, 2H, 2W, C)); optionally also din * (m > 0 ? 1 : slope) into dmask
+template <typename T>
+__global__ void up2_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, T* __restrict__ dmask, const T* __restrict__ m, float slope,
+                               int N, int H, int W, int C) {
+    const int CP = C >> 3, H2 = 2 * H, W2 = 2 * W;
+    const long long total = (long long)N * H * W * CP;
+    const long long in_img = pm_image_elems(H, W, C), out_img = pm_image_elems(H2, W2, C);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CP);
+        const long long pix = idx / CP;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int Y = 2 * y - 1; Y <= 2 * y + 2; ++Y) {
+            if (Y < 0 || Y >= H2) continue;
+            int y0, y1; float ly;
+            up2_src(Y, H, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = 2 * x - 1; X <= 2 * x + 2; ++X) {
+                if (X < 0 || X >= W2) continue;
+                int x0, x1; float lx;
+                up2_src(X, W, x0, x1, lx);
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float f[8];
+                ld8<T>(dout + (long long)n * out_img + pm_off(Y, X, c, W2, C), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (wy * wx) * f[j];
+            }
+        }
+        const long long o = (long long)n * in_img + pm_off(y, x, c, W, C);
+        if (din) st8<T>(din + o, acc);
+        if (dmask) {
+            float mv[8];
+            ld8<T>(m + o, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] *= (mv[j] > 0.f ? 1.f : slope);
+            st8<T>(dmask + o, acc);
+        }
+    }
+}
+
+// out = a + b  (blocked tensors of identical geometry: plain elementwise over the padded image)
+template <typename T>
+__global__ void add_pm_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float f[8], g[8];
+        ld8<T>(a + i * 8, f); ld8<T>(b + i * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        st8<T>(out + i * 8, f);
+    }
+}
+
+// out = g * (m > 0 ? 1 : slope)
+template <typename T>
+__global__ void mask_pm_kernel(const T* __restrict__ g, const T* __restrict__ m, T* __restrict__ out, float slope, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float f[8], mv[8];
+        ld8<T>(g + i * 8, f); ld8<T>(m + i * 8, mv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= (mv[j] > 0.f ? 1.f : slope);
+        st8<T>(out + i * 8, f);
+    }
+}
+
+// ---- spectral norm (torch/nn/utils/spectral_norm.py: compute_weight, n_power_iterations = 1, eps = 1e-12) ----
+// W: (R, K) row-major = weight_orig.reshape(cout, -1).  One workgroup; R <= 512, K <= 8192: the matrices of a discriminator
+// are a few MB and this runs once per forward, so a single-workgroup two-pass mat-vec is plenty.
+__device__ __forceinline__ float blk_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+__global__ __launch_bounds__(1024) void spectral_norm_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v,
+                                                             float* __restrict__ Wn, float* __restrict__ sigma_out, int R, int K,
+                                                             int training, float eps) {
+    __shared__ float red[16];
+    __shared__ float su[512];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int r = tid; r < R; r += nt) su[r] = u[r];
+    __syncthreads();
+    if (training) {
+        // v = normalize(W^T u)
+        float part = 0.f;
+        for (int k = tid; k < K; k += nt) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += W[(long long)r * K + k] * su[r];
+            v[k] = s;
+            part += s * s;
+        }
+        const float nv = fmaxf(sqrtf(blk_sum(part, red)), eps);
+        for (int k = tid; k < K; k += nt) v[k] = v[k] / nv;
+        __syncthreads();
+        // u = normalize(W v): one wave per row
+        const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+        for (int r = wave; r < R; r += nw) {
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += W[(long long)r * K + k] * v[k];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) su[r] = s;
+        }
+        __syncthreads();
+        float p2 = 0.f;
+        for (int r = tid; r < R; r += nt) p2 += su[r] * su[r];
+        const float nu = fmaxf(sqrtf(blk_sum(p2, red)), eps);
+        for (int r = tid; r < R; r += nt) { su[r] = su[r] / nu; u[r] = su[r]; }
+        __syncthreads();
+    }
+    // sigma = u . (W v)
+    {
+        const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+        float part = 0.f;
+        for (int r = wave; r < R; r += nw) {
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += W[(long long)r * K + k] * v[k];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) part += s * su[r];
+        }
+        const float sigma = blk_sum(part, red);
+        if (tid == 0) sigma_out[0] = sigma;
+        const long long n = (long long)R * K;
+        for (long long i = tid; i < n; i += nt) Wn[i] = W[i] / sigma;
+    }
+}
+
+// gradient through weight = W / sigma, sigma = u^T W v (u, v constants):
+//   dW = dWn / sigma - (sum(dWn * W) / sigma^2) * u v^T
+__global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(const float* __restrict__ dWn, const float* __restrict__ W, const float* __restrict__ u,
+                                                                 const float* __restrict__ v, const float* __restrict__ sigma_p,
+                                                                 float* __restrict__ dW, int R, int K) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long long n = (long long)R * K;
+    float part = 0.f;
+    for (long long i = tid; i < n; i += nt) part += dWn[i] * W[i];
+    const float dot = blk_sum(part, red);
+    const float sigma = sigma_p[0];
+    const float coef = dot / (sigma * sigma);
+    for (long long i = tid; i < n; i += nt) {
+        const int r = (int)(i / K), k = (int)(i - (long long)r * K);
+        dW[i] += dWn[i] / sigma - coef * u[r] * v[k];
+    }
+}
+
+// ---- BCE with logits against a constant target, mean reduction (core/losses.py:66-74), value + gradient ----
+__global__ void bce_logits_kernel(const float* __restrict__ x, float* __restrict__ dx, float* __restrict__ loss, long long n, float target, float scale) {
+    float local = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        // max(x,0) - x*t + log(1 + exp(-|x|))   (ATen binary_cross_entropy_with_logits)
+        local += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+        const float sg = 1.f / (1.f + expf(-v));
+        if (dx) dx[i] = scale * (sg - target);
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, local * scale);
+}
+
+inline int wgrid(long long total, int block = 256) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+// ======================================= host side (C++ linkage, used by disc_engine.hip) ==================================
+int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st) {
+    if (!c.x || !c.y || !c.wpack || c.N < 1 || c.H < 1 || c.W < 1 || c.nsl < 1 || c.ncob < 1) return VSR_ERR_BADARG;
+    if ((c.xC & 63) || (c.yC & 63) || c.nsl * 64 > c.xC || c.ncob * 64 > c.yC) return VSR_ERR_BADARG;
+    if ((c.in_step != 1 && c.in_step != 2) || (c.out_step != 1 && c.out_step != 2) || (c.in_step == 2 && c.out_step == 2)) return VSR_ERR_BADARG;
+    WideArgs a = {};
+    a.x = c.x; a.x_nstride = pm_image_elems(c.Hx, c.Wx, c.xC); a.xC = c.xC; a.Hx = c.Hx; a.Wx = c.Wx;
+    a.in_step = c.in_step; a.nsl = c.nsl; a.N = c.N; a.H = c.H; a.W = c.W; a.wpack = c.wpack; a.bias = c.bias;
+    a.y = c.y; a.y_nstride = pm_image_elems(c.Hy, c.Wy, c.yC); a.yC = c.yC; a.Hy = c.Hy; a.Wy = c.Wy; a.out_step = c.out_step; a.ncob = c.ncob;
+    // tap masks over (dy, dx) in {-1,0,1}^2, bit = (dy+1)*3 + (dx+1)
+    auto m1 = [](int lo, int hi) { unsigned m = 0; for (int d = lo; d <= hi; ++d) m |= 1u << (d + 1); return m; };
+    auto m2 = [&](unsigned my, unsigned mx) { unsigned m = 0; for (int y = 0; y < 3; ++y) for (int x = 0; x < 3; ++x) if ((my >> y & 1) && (mx >> x & 1)) m |= 1u << (y * 3 + x); return m; };
+    if (c.in_step == 2) {          // view 0: dy in {0,1}; view 1: dy in {-1,0}
+        for (int v = 0; v < 4; ++v) a.tapmask[v] = m2((v >> 1) ? m1(-1, 0) : m1(0, 1), (v & 1) ? m1(-1, 0) : m1(0, 1));
+    } else if (c.out_step == 2) {  // phase 0: dy in {-1,0}; phase 1: dy in {0,1}
+        for (int p = 0; p < 4; ++p) a.tapmask[p] = m2((p >> 1) ? m1(0, 1) : m1(-1, 0), (p & 1) ? m1(0, 1) : m1(-1, 0));
+    } else {
+        a.tapmask[0] = 0x1FF;
+    }
+    a.act = c.act; a.slope = c.slope; a.y_act = c.y_act; a.res = c.res; a.y_pre = c.y_pre; a.aux = c.aux;
+    const int nph = c.out_step == 2 ? 4 : 1;
+    const long long gz = (long long)c.N * nph * c.ncob;
+    if (gz > 65535) return VSR_ERR_UNSUPPORTED;
+    dim3 grid(cdiv(c.W, TW), cdiv(c.H, TH), (unsigned)gz);
+    if (dtype == VSR_BF16) {
+        constexpr int LDS = NPIX * 8 * 16 + 2 * 64 * 8 * 16;
+        hipLaunchKernelGGL(conv_wide_kernel<bf16_t>, grid, dim3(NTHREADS), LDS, st, a);
+    } else if (dtype == VSR_F32) {
+        constexpr int LDS = NPIX * 8 * 32 + 2 * 64 * 8 * 32;       // 87,040 + 32,768 = 119,808 B
+        static VsrDevOnce once;
+        { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv_wide_kernel<float>), LDS); if (rc != VSR_OK) return rc; }
+        hipLaunchKernelGGL(conv_wide_kernel<float>, grid, dim3(NTHREADS), LDS, st, a);
+    } else {
+        return VSR_ERR_BADARG;
+    }
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+long long vsr_wide_pack_elems(int cout, int cin, int mode) {
+    const long long blocks = (mode == 1 || mode == 3) ? 4LL * (cout / 64) * (cin / 64) : (long long)(cout / 64) * (cin / 64);
+    return blocks * 9 * 4096;
+}
+
+int vsr_launch_pack_wide(int dtype, const float* w, void* dst, int cout, int cin, int mode, hipStream_t st) {
+    if (!w || !dst || (cout & 63) || (cin & 63) || mode < 0 || mode > 3) return VSR_ERR_BADARG;
+    const long long total = vsr_wide_pack_elems(cout, cin, mode);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(pack_wide_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)dst, cout, cin, mode, total);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(pack_wide_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)dst, cout, cin, mode, total);
+    else return VSR_ERR_BADARG;
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_wgrad_reduce_s2(const float* slab, int nwg, int slab_stride, float* gw, int cin_total, int co0, int ci0, int view, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_reduce_s2_kernel, dim3(cdiv(9 * 64 * 64, 256)), dim3(256), 0, st, slab, nwg, slab_stride, gw, cin_total, co0, ci0, view);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_up2_fwd(int dtype, const void* a, const void* b, void* out, int N, int H, int W, int C, hipStream_t st) {
+    if (!a || !out || N < 1 || H < 1 || W < 1 || (C & 7)) return VSR_ERR_BADARG;
+    const long long total = (long long)N * 4 * H * W * (C / 8);
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_fwd_kernel<bf16_t>, dim3(wgrid(total)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, N, H, W, C);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_fwd_kernel<float>, dim3(wgrid(total)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, H, W, C);
+    else return VSR_ERR_BADARG;
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_up2_bwd(int dtype, const void* dout, void* din, void* dmask, const void* m, float slope, int N, int H, int W, int C, hipStream_t st) {
+    if (!dout || (!din && !dmask) || (dmask && !m) || N < 1 || H < 1 || W < 1 || (C & 7)) return VSR_ERR_BADARG;
+    const long long total = (long long)N * H * W * (C / 8);
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_bwd_kernel<bf16_t>, dim3(wgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)din, (bf16_t*)dmask, (const bf16_t*)m, slope, N, H, W, C);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(wgrid(total)), dim3(256), 0, st, (const float*)dout, (float*)din, (float*)dmask, (const float*)m, slope, N, H, W, C);
+    else return VSR_ERR_BADARG;
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_add_pm(int dtype, const void* a, const void* b, void* out, long long elems, hipStream_t st) {
+    const long long n8 = elems / 8;
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(add_pm_kernel<bf16_t>, dim3(wgrid(n8)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n8);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(add_pm_kernel<float>, dim3(wgrid(n8)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n8);
+    else return VSR_ERR_BADARG;
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_mask_pm(int dtype, const void* g, const void* m, void* out, float slope, long long elems, hipStream_t st) {
+    const long long n8 = elems / 8;
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(mask_pm_kernel<bf16_t>, dim3(wgrid(n8)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)m, (bf16_t*)out, slope, n8);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(mask_pm_kernel<float>, dim3(wgrid(n8)), dim3(256), 0, st, (const float*)g, (const float*)m, (float*)out, slope, n8);
+    else return VSR_ERR_BADARG;
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+extern "C" {
+
+int vsr_spectral_norm(const float* w_orig, float* u, float* v, float* w_out, float* sigma, int rows, int cols, int training, void* stream) {
+    if (!w_orig || !u || !v || !w_out || !sigma || rows < 1 || rows > 512 || cols < 1) return VSR_ERR_BADARG;
+    hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_orig, u, v, w_out, sigma, rows, cols, training, 1e-12f);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v, const float* sigma, float* dw_orig,
+                               int rows, int cols, void* stream) {
+    if (!dw || !w_orig || !u || !v || !sigma || !dw_orig || rows < 1 || cols < 1) return VSR_ERR_BADARG;
+    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dw, w_orig, u, v, sigma, dw_orig, rows, cols);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_bce_with_logits(const float* x, float target, float* dx, float* loss, long long numel, void* stream) {
+    if (!x || !loss || numel < 1) return VSR_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK_RET(hipMemsetAsync(loss, 0, sizeof(float), st));
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(wgrid(numel)), dim3(256), 0, st, x, dx, loss, numel, target, 1.0f / (float)numel);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+}  // extern "C"

@@ -42,4 +42,22 @@ int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP
 int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps,
                                 hipStream_t st);
 
+// ---- GAN side (conv_wide.hip) ----
+struct VsrWideConv {
+    const void* x; int xC, Hx, Wx, in_step, nsl;
+    int N, H, W;
+    const void* wpack; const float* bias;
+    void* y; int yC, Hy, Wy, out_step, ncob;
+    int act; float slope;
+    void* y_act; const void* res; void* y_pre; const void* aux;
+};
+int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st);
+long long vsr_wide_pack_elems(int cout, int cin, int mode);
+int vsr_launch_pack_wide(int dtype, const float* w, void* dst, int cout, int cin, int mode, hipStream_t st);
+int vsr_launch_wgrad_reduce_s2(const float* slab, int nwg, int slab_stride, float* gw, int cin_total, int co0, int ci0, int view, hipStream_t st);
+int vsr_launch_up2_fwd(int dtype, const void* a, const void* b, void* out, int N, int H, int W, int C, hipStream_t st);
+int vsr_launch_up2_bwd(int dtype, const void* dout, void* din, void* dmask, const void* m, float slope, int N, int H, int W, int C, hipStream_t st);
+int vsr_launch_mask_pm(int dtype, const void* g, const void* m, void* out, float slope, long long elems, hipStream_t st);
+int vsr_launch_add_pm(int dtype, const void* a, const void* b, void* out, long long elems, hipStream_t st);
+
 #define VSR_WGRAD_NWG 512   // persistent wgrad workgroups: 2 per CU x 256 CUs

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
                     if (vy < a.H && vx < a.W) {
                         const long long o = (long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox);
-                        c0 = base[o]; c1 = base[o + plane]; c2 = base[o + 2 * plane];
+                        const int pc = a.dy_planar_c ? a.dy_planar_c : 3;
+                        c0 = base[o]; c1 = pc > 1 ? base[o + plane] : 0.f; c2 = pc > 2 ? base[o + 2 * plane] : 0.f;
                     }
                     bsum[0] += c0; bsum[1] += c1; bsum[2] += c2;
                     *reinterpret_cast<chunk_t*>(ly + (p * 2 + 0) * CHB) = wchunk3(c0, c1, c2, (T*)nullptr);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                     const int vy = ty0 + ty, vx = tx0 + tx;
                     chunk_t v = wzero<T>();
                     if (vy < a.H && vx < a.W) {
-                        const long long o = pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c, a.Wy, COUT);
+                        const long long o = pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c + a.dy_coff, a.Wy, a.dy_ctotal ? a.dy_ctotal : COUT);
                         v = *reinterpret_cast<const chunk_t*>(base + o);
                     }
                     chunk_sum(v, bsum);
@@ -606,6 +607,8 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
     if (role == 1) {
         // =================== producers ===================
         const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
+        // X / dY may be 64-channel SLICES of wider tensors (the discriminator's 128..512-channel layers): chunks per pixel
+        const int xcp = (a.x_ctotal ? a.x_ctotal : 64) >> 3, ycp = (a.dy_ctotal ? a.dy_ctotal : 64) >> 3;
         constexpr int NPIECE = (DX_PIECES + DY_PIECES) / 4;           // 20 per wave
         static_assert((DX_PIECES + DY_PIECES) % 4 == 0, "even split over 4 producer waves");
         int rel[NPIECE];
@@ -618,14 +621,14 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 const int row = idx / (8 * XS), rem = idx - row * (8 * XS);
                 const int c = rem / XS, tx = rem - c * XS;
                 const int dx = (tx - 1) * a.x_step + a.x_ox;
-                rel[i] = (((((row - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+                rel[i] = (((((row - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * xcp + c) * 256 + (dx & 31) * 8) * 2;
                 if (tx >= TW + 2) padmask |= 1u << i;
             } else {
                 const int idx = (piece - DX_PIECES) * 64 + lane;
                 const int row = idx / (8 * YS), rem = idx - row * (8 * YS);
                 const int c = rem / YS, tx = rem - c * YS;
                 const int dx = tx * a.dy_step + a.dy_ox;
-                rel[i] = ((((row * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+                rel[i] = ((((row * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * ycp + c) * 256 + (dx & 31) * 8) * 2;
                 if (tx >= TW) padmask |= 1u << i;
             }
         }
@@ -637,8 +640,8 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
             const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
             const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
             const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
-            const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, 0, a.Wx, 64) * 2;      // tx0*step: multiple of 32
-            const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, 0, a.Wy, 64) * 2;
+            const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, a.x_coff, a.Wx, xcp * 8) * 2;      // tx0*step: multiple of 32
+            const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, a.dy_coff, a.Wy, ycp * 8) * 2;
             char* lxs = smem + s * DSET;
             const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;              // wave-uniform
 #pragma unroll
@@ -844,7 +847,8 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
         if (v1 < 0) { const char* e = getenv("VSRLAB_AMD_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
         if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2) {
             *nslabs = nwg / 2;                                 // one 512-thread workgroup per CU, one slab each
-            return v1 ? launch_wgrad_dma(a, nwg / 2, st) : launch_wgrad_pc(a, nwg / 2, st);
+            const bool sliced = a.x_ctotal || a.x_coff || a.dy_ctotal || a.dy_coff;
+            return (v1 && !sliced) ? launch_wgrad_dma(a, nwg / 2, st) : launch_wgrad_pc(a, nwg / 2, st);
         }
     }
 #define X(KS, CX, XP, COUT, DP)                                                                        \

@@ -520,3 +520,116 @@ def charbonnier_loss(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-9) -> tor
     if y.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError("HIP Charbonnier differentiates w.r.t. its first argument only")
     return _CharbonnierFn.apply(x, y, eps)
+
+
+# --------------------------------------------------------------------------------------------- #
+# GAN side (BASELINE config 3): UNetDiscriminator + spectral norm + BCE-with-logits
+# (reference: vsr/models/RealBasicVSR/modules/unet-discriminator.py:4-31, core/modules/conv.py:6-13,
+#  core/losses.py:66-74)
+# --------------------------------------------------------------------------------------------- #
+_DISC_SPECTRAL = [(128, 64, 4), (256, 128, 4), (512, 256, 4), (256, 512, 3), (128, 256, 3), (64, 128, 3), (64, 64, 3), (64, 64, 3)]
+
+
+class _DiscriminatorFn(torch.autograd.Function):
+    """logits = UNetDiscriminator(img).  Inputs: img, then conv_0.weight, conv_0.bias, the 8 weight_orig tensors,
+    conv_9.weight, conv_9.bias (autograd leaves), then the 8 (u, v) buffer pairs (updated IN PLACE by the training-mode
+    power iteration, like torch.nn.utils.spectral_norm's forward pre-hook)."""
+
+    @staticmethod
+    def forward(ctx, img, dtype, training, need_bwd, *tensors):
+        from ._lib import DiscDesc
+        lib = _lib.load()
+        n, c, h, w = img.shape
+        params, bufs = tensors[:12], tensors[12:]
+        dev = img.device
+        img32 = _f32c(img)
+        p32 = [_f32c(p) for p in params]
+        eff, sig, uv = [], [], []
+        for k, (co, ci, ks) in enumerate(_DISC_SPECTRAL):
+            worig = p32[2 + k]
+            u, v = bufs[2 * k], bufs[2 * k + 1]
+            weff = torch.empty_like(worig)
+            sigma = torch.empty(1, dtype=torch.float32, device=dev)
+            _lib.check(lib.vsr_spectral_norm(_ptr(worig), _ptr(u), _ptr(v), _ptr(weff), _ptr(sigma), co, ci * ks * ks, int(training),
+                                             _stream()), "spectral_norm")
+            eff.append(weff)
+            sig.append(sigma)
+            uv.append((u.detach().clone(), v.detach().clone()) if need_bwd else None)   # the constants of THIS forward's graph
+        desc = DiscDesc(n, h, w, 64, dtype)
+        nbytes = lib.vsr_disc_workspace_bytes(ctypes.byref(desc), int(need_bwd))
+        if nbytes == 0:
+            raise RuntimeError(f"vsrlab_amd: unsupported discriminator input for the HIP path: {(n, c, h, w)} "
+                               "(3-channel frames, height and width multiples of 8, mid_ch = 64)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        call = [p32[0], p32[1]] + eff + [p32[10], p32[11]]
+        out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
+        _lib.check(lib.vsr_disc_forward(ctypes.byref(desc), _ptr_array(call), 12, _ptr(img32), _ptr(out), _ptr(ws), ws.numel(),
+                                        int(need_bwd), _stream()), "disc_forward")
+        ctx.need_bwd = need_bwd
+        if need_bwd:
+            ctx.ws, ctx.img32, ctx.p32, ctx.sig, ctx.uv, ctx.desc_args = ws, img32, p32, sig, uv, (n, h, w, 64, dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import DiscDesc
+        if not ctx.need_bwd:
+            raise RuntimeError("vsrlab_amd: backward through a discriminator forward that ran without need_backward")
+        if ctx.ws is None:
+            raise RuntimeError("vsrlab_amd: trying to backward through the discriminator graph a second time")
+        lib = _lib.load()
+        desc = DiscDesc(*ctx.desc_args)
+        p32 = ctx.p32
+        need_p = [bool(ctx.needs_input_grad[4 + k]) for k in range(12)]
+        any_p = any(need_p)
+        geff = [torch.zeros_like(p) if any_p else None for p in p32]
+        dimg = torch.empty_like(ctx.img32) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.vsr_disc_backward(ctypes.byref(desc), _ptr_array(geff), 12, _ptr(ctx.img32), _ptr(_f32c(dout)), _ptr(dimg),
+                                         _ptr(ctx.ws), ctx.ws.numel(), _stream()), "disc_backward")
+        grads = [None] * 12
+        if any_p:
+            grads[0], grads[1], grads[10], grads[11] = geff[0], geff[1], geff[10], geff[11]
+            for k, (co, ci, ks) in enumerate(_DISC_SPECTRAL):
+                gorig = torch.zeros_like(p32[2 + k])
+                u, v = ctx.uv[k]
+                _lib.check(lib.vsr_spectral_norm_backward(_ptr(geff[2 + k]), _ptr(p32[2 + k]), _ptr(u), _ptr(v), _ptr(ctx.sig[k]),
+                                                          _ptr(gorig), co, ci * ks * ks, _stream()), "spectral_norm_backward")
+                grads[2 + k] = gorig
+        ctx.ws = None
+        return (dimg, None, None, None) + tuple(g if need_p[k] else None for k, g in enumerate(grads)) + (None,) * 16
+
+
+def discriminator_forward(img: torch.Tensor, params: Sequence[torch.Tensor], buffers: Sequence[torch.Tensor], training: bool,
+                          compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """``params``: conv_0.weight, conv_0.bias, conv_1..8 ``weight_orig``, conv_9.weight, conv_9.bias; ``buffers``:
+    (weight_u, weight_v) of conv_1..8, updated in place when ``training``."""
+    _require_gpu(img)
+    if img.dim() != 4 or img.shape[1] != 3:
+        raise ValueError("discriminator input must be (N,3,H,W)")
+    if len(params) != 12 or len(buffers) != 16:
+        raise ValueError("expected 12 parameter tensors and 16 spectral-norm buffers")
+    need_bwd = torch.is_grad_enabled() and (img.requires_grad or any(p.requires_grad for p in params))
+    return _DiscriminatorFn.apply(img, resolve_dtype(compute_dtype), bool(training), need_bwd, *params, *buffers)
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target):
+        lib = _lib.load()
+        x32 = _f32c(x)
+        dx = torch.empty_like(x32)
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        _lib.check(lib.vsr_bce_with_logits(_ptr(x32), float(target), _ptr(dx), _ptr(loss), x32.numel(), _stream()), "bce_with_logits")
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None
+
+
+def bce_with_logits_const(x: torch.Tensor, target: float) -> torch.Tensor:
+    """mean BCE-with-logits of ``x`` against the constant ``target`` (AdversarialLoss, core/losses.py:70-73)."""
+    _require_gpu(x)
+    return _BCEFn.apply(x, float(target))
