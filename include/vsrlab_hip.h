@@ -212,6 +212,37 @@ int vsr_spectral_norm_backward(const float* dw, const float* w_orig, const float
 /* AdversarialLoss's core (core/losses.py:66-74): loss[0] = mean BCE-with-logits(x, target); dx (optional) = its gradient */
 int vsr_bce_with_logits(const float* x, float target, float* dx, float* loss, long long numel, void* stream);
 
+/* ---- VRT window attention (BASELINE config 5; csrc/window_attention.hip) ------------------------------------------
+ * The core of WindowAttention.attention (vsr/models/VRT/modules/window_attention.py:140-162):
+ *     out = softmax((q * scale) k^T [+ bias[head]] [+ mask[window % nW]]) v
+ * for every (window b, head h), fused on the matrix cores (no N x N tensor in HBM).  qkv is the output of the qkv Linear,
+ * (B, N, 3, heads, head_dim) contiguous in `dtype`; queries are tokens [q0, q0+Nq), keys / values tokens [k0, k0+Nk)
+ * (self attention: both all N tokens; mutual attention of a 2-frame window: the two halves, :128-134), and the result
+ * goes to rows [o0, o0+Nq), channels [c_off, c_off + heads*head_dim) of out (B, N, Cout) -- where the reference's torch.cat
+ * (:131-134) would put it.  head_dim <= 32; Nq, Nk multiples of 32, <= 384.
+ * bias: dense fp32 (heads, Nq, Nk) or NULL (vsr_rpb_gather builds it from relative_position_bias_table, :146-148);
+ * mask: fp32 (nW, Nm, Nm) from compute_mask (:61-77) or NULL -- its top-left Nq x Nk block is used, as the reference does.  */
+typedef struct VsrAttnDesc {
+    int B, N, heads, head_dim;
+    int q0, k0, o0, Nq, Nk;
+    int Cout, c_off;
+    int nW, Nm;
+    float scale;
+    int dtype;
+    int mask_packed;     /* 1: `mask` is vsr_mask_pack's bit-packed form (uint32 [nW][Nm][Nm/32], bit = entry != 0) and */
+    float mask_value;    /*    every non-zero entry equals mask_value (-100 for compute_mask); Nq = Nk in {64, 128} only */
+} VsrAttnDesc;
+int vsr_mask_pack(const float* mask, unsigned* bits, int nW, int Nm, void* stream);
+int vsr_window_attention_fwd(const VsrAttnDesc* d, const void* qkv, const float* bias, const float* mask, void* out,
+                             float* lse /* (B, heads, Nq) fp32, needed by the backward; may be NULL */, void* stream);
+/* dqkv (layout of qkv): d/dq for tokens [q0, q0+Nq) and d/dk, d/dv for tokens [k0, k0+Nk) are WRITTEN (other elements
+ * untouched); dbias (heads, Nq, Nk) fp32 or NULL is ACCUMULATED into (atomics); delta: scratch (B, heads, Nq) fp32.   */
+int vsr_window_attention_bwd(const VsrAttnDesc* d, const void* qkv, const float* bias, const float* mask, const void* dout,
+                             const float* lse, float* delta, void* dqkv, float* dbias, void* stream);
+/* dense[h][i][j] = table[index[i*idx_stride + j]][h] (index: int64, the module's relative_position_index) / its adjoint */
+int vsr_rpb_gather(const float* table, const long long* index, int idx_stride, float* dense, int heads, int N, void* stream);
+int vsr_rpb_scatter(const float* ddense, const long long* index, int idx_stride, float* dtable, int heads, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,12 @@ def keyed_tensor(key: str, shape: Tuple[int, ...]) -> Tensor:
         return v * 0.01
     if key.endswith(("weight_u", "weight_v")):          # spectral_norm's power-iteration vectors: unit norm
         return v / v.norm()
+    if key.endswith("relative_position_bias_table"):    # VRT window attention: O(1) biases so that they matter
+        return v * 0.5
+    if len(shape) == 1:                                 # LayerNorm weight
+        return 1.0 + 0.1 * v
+    if len(shape) == 2:                                 # nn.Linear weight (out, in)
+        return v * (1.0 / math.sqrt(shape[1]))
     fan_in = shape[1] * shape[2] * shape[3]
     # 0.7/sqrt(fan_in) keeps a 30-block trunk O(1); the SPyNet convs get a larger gain so
     # that the synthetic flows reach a few pixels and the warps are genuinely exercised

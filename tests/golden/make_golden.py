@@ -320,8 +320,66 @@ def disc():
     print("gan_step", len(store))
 
 
+def vrt():
+    """VRT window attention and one shifted TMSA block (vsr/models/VRT/modules/window_attention.py:100-188, :61-77;
+    tmsa.py:9-124), fp64 reference.  dim 120 / 6 heads = head_dim 20, window (2,8,8) with mutual attention (the VRT
+    stage configuration) and dim 180 / 6 = 30, window (6,8,8) without (the RTMSA configuration).  Parameters are keyed;
+    the buffers (relative_position_index, position_bias) are the module's own deterministic values."""
+    torch.set_num_threads(8)
+    import_reference()
+    from vsrlab.vsr.models.VRT.modules import tmsa as ref_tmsa
+    from vsrlab.vsr.models.VRT.modules import window_attention as ref_wa
+    from oracle.basicvsr_oracle import keyed_tensor
+
+    def keyed_params(m):
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                p.copy_(keyed_tensor(k, tuple(p.shape)))
+        return m.double()
+
+    store = {}
+
+    def put_grads(tag, module):          # small gradients in full, every gradient by norm and seeded projection
+        for k, p in module.named_parameters():
+            g = p.grad.detach()
+            name = k.replace(".", "__")
+            if g.numel() <= 8192:
+                store[f"{tag}__grad__{name}"] = g.float().numpy()
+            store[f"{tag}__gnorm__{name}"] = np.asarray(float(g.norm()))
+            store[f"{tag}__gproj__{name}"] = np.asarray(float((g * proj_vector(k, tuple(g.shape))).sum()))
+
+    for tag, dim, ws, mut, B_ in (("a", 120, (2, 8, 8), True, 4), ("b", 180, (6, 8, 8), False, 2)):
+        m = keyed_params(ref_wa.WindowAttention(dim, ws, 6, qkv_bias=True, qk_scale=None, mut_attn=mut))
+        N = ws[0] * ws[1] * ws[2]
+        x = rand(50 + ord(tag), B_, N, dim, lo=-1, hi=1).double().requires_grad_(True)
+        mask = ref_wa.compute_mask(2 * ws[0], 16, 16, ws, tuple(i // 2 for i in ws), "cpu")[:2].double() if tag == "a" else None
+        y = m(x, mask)
+        cot = rand(60 + ord(tag), B_, N, dim, lo=-1, hi=1).double()
+        (y * cot).sum().backward()
+        store[f"{tag}__out"] = y.detach().float().numpy()
+        store[f"{tag}__dx"] = x.grad.detach().float().numpy()
+        put_grads(tag, m)
+        store[f"{tag}__seed_x"], store[f"{tag}__seed_cot"] = np.asarray(50 + ord(tag)), np.asarray(60 + ord(tag))
+    # one shifted TMSA block on a volume that needs padding in H (20 -> 24) and has 2 x 3 x 2 windows
+    blk = keyed_params(ref_tmsa.TMSA(120, (4, 20, 16), 6, window_size=(2, 8, 8), shift_size=(1, 4, 4), mut_attn=True, mlp_ratio=2.,
+                                     qkv_bias=True))
+    x = rand(70, 1, 4, 20, 16, 120, lo=-1, hi=1).double().requires_grad_(True)
+    mask = ref_wa.compute_mask(4, 24, 16, (2, 8, 8), (1, 4, 4), "cpu").double()
+    y = blk(x, mask)
+    cot = rand(71, 1, 4, 20, 16, 120, lo=-1, hi=1).double()
+    (y * cot).sum().backward()
+    store["t__out"], store["t__dx"] = y.detach().float().numpy(), x.grad.detach().float().numpy()
+    store["t__mask"] = mask.float().numpy()
+    put_grads("t", blk)
+    store["t__keys"] = np.asarray(sorted(blk.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "vrt_window_attention.npz"), **store)
+    print("vrt_window_attention", len(store))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "vrt"):
+        vrt()
     if which in ("all", "disc"):
         disc()
     if which in ("all", "realtrain"):

@@ -25,6 +25,12 @@ class DiscDesc(ctypes.Structure):
     _fields_ = [("n", c_int), ("h", c_int), ("w", c_int), ("mid_ch", c_int), ("dtype", c_int)]
 
 
+class AttnDesc(ctypes.Structure):
+    """struct VsrAttnDesc (include/vsrlab_hip.h)."""
+    _fields_ = [(k, c_int) for k in ("B", "N", "heads", "head_dim", "q0", "k0", "o0", "Nq", "Nk", "Cout", "c_off", "nW", "Nm")] + \
+               [("scale", c_float), ("dtype", c_int), ("mask_packed", c_int), ("mask_value", c_float)]
+
+
 _P = c_void_p
 _SIGNATURES = {
     "vsr_abi_version": (c_int, []),
@@ -61,6 +67,11 @@ _SIGNATURES = {
     "vsr_spectral_norm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vsr_spectral_norm_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "vsr_bce_with_logits": (c_int, [_P, c_float, _P, _P, c_longlong, _P]),
+    "vsr_window_attention_fwd": (c_int, [ctypes.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
+    "vsr_window_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vsr_mask_pack": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vsr_rpb_gather": (c_int, [_P, _P, c_int, _P, c_int, c_int, _P]),
+    "vsr_rpb_scatter": (c_int, [_P, _P, c_int, _P, c_int, c_int, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -633,3 +633,116 @@ def bce_with_logits_const(x: torch.Tensor, target: float) -> torch.Tensor:
     """mean BCE-with-logits of ``x`` against the constant ``target`` (AdversarialLoss, core/losses.py:70-73)."""
     _require_gpu(x)
     return _BCEFn.apply(x, float(target))
+
+
+# --------------------------------------------------------------------------------------------- #
+# VRT window attention core (reference: vsr/models/VRT/modules/window_attention.py:116-162)
+# --------------------------------------------------------------------------------------------- #
+_MASK_BITS = {}
+
+
+def _packed_mask(m32: torch.Tensor):
+    """(bits, value) of a {0, value} attention mask (compute_mask's 0 / -100), or None if the mask has other values.
+    Cached per mask tensor: VRT builds one mask per stage shape (window_attention.py:61 is lru_cached)."""
+    key = (m32.data_ptr(), tuple(m32.shape), m32._version)
+    hit = _MASK_BITS.get(key)
+    if hit is None:
+        nW, Nm, _ = m32.shape
+        value = float(m32.min().item())                       # one host sync per distinct mask
+        ok = Nm % 32 == 0 and value != 0.0 and bool(((m32 == 0) | (m32 == value)).all().item())
+        if ok:
+            bits = torch.empty((nW, Nm, Nm // 32), dtype=torch.int32, device=m32.device)
+            _lib.check(_lib.load().vsr_mask_pack(_ptr(m32), _ptr(bits), nW, Nm, _stream()), "mask_pack")
+            hit = (bits, value, m32)                           # keeps m32 alive: the key's data_ptr stays unique
+        else:
+            hit = (None, 0.0, m32)
+        if len(_MASK_BITS) > 64:
+            _MASK_BITS.clear()
+        _MASK_BITS[key] = hit
+    return hit[0], hit[1]
+
+
+class _WindowAttentionFn(torch.autograd.Function):
+    """x_out = [mutual attention | self attention] of WindowAttention.forward, given the outputs of the qkv Linears.
+
+    qkv_self (B_, N, 3C) ; qkv_mut (B_, N, 3C) or None ; table: relative_position_bias_table ((2Wd-1)(2Wh-1)(2Ww-1), heads);
+    index: relative_position_index (int64) ; mask (nW, Nm, Nm) or None.  Returns (B_, N, 2C) with mutual attention,
+    (B_, N, C) without -- the tensor the reference builds with torch.cat (:131-134) before ``proj``."""
+
+    @staticmethod
+    def forward(ctx, qkv_self, qkv_mut, table, index, mask, heads, scale, dtype):
+        from ._lib import AttnDesc
+        lib = _lib.load()
+        tdt = _TORCH_DT[dtype]
+        B, N, C3 = qkv_self.shape
+        C = C3 // 3
+        hd = C // heads
+        mut = qkv_mut is not None
+        dev = qkv_self.device
+        qs = qkv_self.detach().to(tdt).contiguous()
+        qm = qkv_mut.detach().to(tdt).contiguous() if mut else None
+        Cout = 2 * C if mut else C
+        out = torch.empty((B, N, Cout), dtype=tdt, device=dev)
+        idx = index.contiguous()
+        dense = torch.empty((heads, N, N), dtype=torch.float32, device=dev)
+        _lib.check(lib.vsr_rpb_gather(_ptr(_f32c(table)), _ptr(idx), idx.shape[1], _ptr(dense), heads, N, _stream()), "rpb_gather")
+        m32 = _f32c(mask) if mask is not None else None
+        nW, Nm = (m32.shape[0], m32.shape[1]) if m32 is not None else (1, 0)
+        if m32 is not None and (B % nW != 0 or Nm < N):
+            raise ValueError("attention mask does not match the windows")
+        calls = [(qs, 0, 0, 0, N, N, C if mut else 0, dense)]
+        if mut:
+            h2 = N // 2
+            calls += [(qm, h2, 0, 0, h2, h2, 0, None),        # x1_aligned = attention(q2, k1, v1) -> tokens [0, N/2)
+                      (qm, 0, h2, h2, h2, h2, 0, None)]       # x2_aligned = attention(q1, k2, v2) -> tokens [N/2, N)
+        lses = []
+        bits, mval = _packed_mask(m32) if m32 is not None else (None, 0.0)
+        for (t, q0, k0, o0, nq, nk, coff, bias) in calls:
+            packed = bits is not None and nq == nk and nq in (64, 128)
+            d = AttnDesc(B, N, heads, hd, q0, k0, o0, nq, nk, Cout, coff, nW, Nm, float(scale), dtype, int(packed), mval)
+            lse = torch.empty((B, heads, nq), dtype=torch.float32, device=dev)
+            _lib.check(lib.vsr_window_attention_fwd(ctypes.byref(d), _ptr(t), _ptr(bias), _ptr(bits if packed else m32), _ptr(out), _ptr(lse),
+                                                    _stream()), "window_attention_fwd")
+            lses.append(lse)
+        ctx.mask_bits, ctx.mask_value = bits, mval
+        ctx.save_for_backward(qs, qm, dense, m32, idx, *lses)
+        ctx.meta = (B, N, C, heads, hd, mut, Cout, nW, Nm, float(scale), dtype, tuple(table.shape), qkv_self.dtype)
+        ctx.calls = [(c[1], c[2], c[3], c[4], c[5], c[6], c[7] is not None) for c in calls]
+        return out.to(qkv_self.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import AttnDesc
+        lib = _lib.load()
+        qs, qm, dense, m32, idx, *lses = ctx.saved_tensors
+        B, N, C, heads, hd, mut, Cout, nW, Nm, scale, dtype, tshape, in_dt = ctx.meta
+        tdt = _TORCH_DT[dtype]
+        dev = dout.device
+        do = dout.detach().to(tdt).contiguous()
+        dqs = torch.empty_like(qs)
+        dqm = torch.empty_like(qm) if mut else None
+        ddense = torch.zeros_like(dense)
+        for (q0, k0, o0, nq, nk, coff, has_bias), lse, (src, dst) in zip(ctx.calls, lses, [(qs, dqs)] + [(qm, dqm)] * 2):
+            packed = ctx.mask_bits is not None and nq == nk and nq in (64, 128)
+            d = AttnDesc(B, N, heads, hd, q0, k0, o0, nq, nk, Cout, coff, nW, Nm, scale, dtype, int(packed), ctx.mask_value)
+            delta = torch.empty((B, heads, nq), dtype=torch.float32, device=dev)
+            _lib.check(lib.vsr_window_attention_bwd(ctypes.byref(d), _ptr(src), _ptr(dense if has_bias else None),
+                                                    _ptr(ctx.mask_bits if packed else m32), _ptr(do),
+                                                    _ptr(lse), _ptr(delta), _ptr(dst), _ptr(ddense if has_bias else None), _stream()),
+                       "window_attention_bwd")
+        dtable = None
+        if ctx.needs_input_grad[2]:
+            dtable = torch.zeros(tshape, dtype=torch.float32, device=dev)
+            _lib.check(lib.vsr_rpb_scatter(_ptr(ddense), _ptr(idx), idx.shape[1], _ptr(dtable), heads, N, _stream()), "rpb_scatter")
+        return dqs.to(in_dt), (dqm.to(in_dt) if mut else None), dtable, None, None, None, None, None
+
+
+def window_attention_core(qkv_self: torch.Tensor, qkv_mut: Optional[torch.Tensor], table: torch.Tensor, index: torch.Tensor,
+                          mask: Optional[torch.Tensor], heads: int, scale: float, compute_dtype: Optional[str] = None) -> torch.Tensor:
+    _require_gpu(qkv_self)
+    B, N, C3 = qkv_self.shape
+    if C3 % (3 * heads) != 0:
+        raise ValueError("qkv width must be 3 * heads * head_dim")
+    if (C3 // 3 // heads) > 32 or N % 32 != 0 or N > 384 or (qkv_mut is not None and N % 64 != 0):
+        raise NotImplementedError("HIP window attention: head_dim <= 32 and windows of 64..384 tokens (VRT's (2,8,8) / (6,8,8))")
+    return _WindowAttentionFn.apply(qkv_self, qkv_mut, table, index[:N, :N], mask, heads, scale, resolve_dtype(compute_dtype))

@@ -1,0 +1,60 @@
+"""``TMSA`` -- Temporal Mutual Self Attention block (vsrlab ``src/vsr/models/VRT/modules/tmsa.py:9-124``), with the
+HIP window attention inside.  Same constructor, parameter names (``norm1``, ``attn.*``, ``norm2``, ``mlp.*``) and
+``forward(x, mask_matrix)`` on (B, D, H, W, C).  ``drop_path`` > 0 (stochastic depth) is a training-time regulariser
+outside the hot path and is not offered."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .window_attention import Mlp_GEGLU, WindowAttention, get_window_size, window_partition, window_reverse
+
+
+class TMSA(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size=(6, 8, 8), shift_size=(0, 0, 0), mut_attn=True, mlp_ratio=2.,
+                 qkv_bias=True, qk_scale=None, drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if drop_path > 0.:
+            raise NotImplementedError("stochastic depth is not on the HIP path")
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size = window_size, shift_size
+        assert all(0 <= s < w for s, w in zip(shift_size, window_size)), "shift_size must be in range [0, window_size]"
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, window_size=self.window_size, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                    mut_attn=mut_attn)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp_GEGLU(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
+
+    def forward_part1(self, x, mask_matrix):
+        B, D, H, W, C = x.shape
+        window_size, shift_size = get_window_size((D, H, W), self.window_size, self.shift_size)
+        x = self.norm1(x)
+        pad_d1 = (window_size[0] - D % window_size[0]) % window_size[0]
+        pad_b = (window_size[1] - H % window_size[1]) % window_size[1]
+        pad_r = (window_size[2] - W % window_size[2]) % window_size[2]
+        x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b, 0, pad_d1), mode='constant')
+        _, Dp, Hp, Wp, _ = x.shape
+        if any(i > 0 for i in shift_size):
+            shifted_x = torch.roll(x, shifts=(-shift_size[0], -shift_size[1], -shift_size[2]), dims=(1, 2, 3))
+            attn_mask = mask_matrix
+        else:
+            shifted_x, attn_mask = x, None
+        x_windows = window_partition(shifted_x, window_size)
+        attn_windows = self.attn(x_windows, mask=attn_mask)
+        attn_windows = attn_windows.view(-1, *(window_size + (C,)))
+        shifted_x = window_reverse(attn_windows, window_size, B, Dp, Hp, Wp)
+        if any(i > 0 for i in shift_size):
+            x = torch.roll(shifted_x, shifts=(shift_size[0], shift_size[1], shift_size[2]), dims=(1, 2, 3))
+        else:
+            x = shifted_x
+        if pad_d1 > 0 or pad_r > 0 or pad_b > 0:
+            x = x[:, :D, :H, :W, :]
+        return x
+
+    def forward_part2(self, x):
+        return self.mlp(self.norm2(x))
+
+    def forward(self, x, mask_matrix):
+        x = x + self.forward_part1(x, mask_matrix)
+        x = x + self.forward_part2(x)
+        return x
