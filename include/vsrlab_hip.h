@@ -106,6 +106,19 @@ int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* param
 int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int nparams,
                         const float* dflow, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Forward of the canonical SPyNet variants: last_relu = 0 drops the ReLU the RealBasicVSR copy has after every level's last
+ * conv (vsr/models/VRT/modules/spynet.py:68-157); level_out: HOST array of 6 device pointers (NULL = not wanted), entry l
+ * receives level l's flow resized to (N,2, h >> (5-l), w >> (5-l)) -- VRT's return_levels.  Same workspace query.      */
+int vsr_spynet_forward_ex(int N, int h, int w, int dtype, const float* const* params, int nparams, const float* ref,
+                          const float* supp, int last_relu, float* const* level_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* The same plus the gradient w.r.t. the two input frames (through the border warps, the image pyramid, the /32 resize and
+ * the normalisation): dref, dsupp (N,3,h,w) fp32 are WRITTEN (either may be NULL); grads may be NULL (frozen flow net);
+ * params: the forward's 62 tensors.                                                                                 */
+int vsr_spynet_backward_ex(int N, int h, int w, int dtype, const float* const* params, float* const* grads, int nparams,
+                           const float* dflow, float* dref, float* dsupp, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ---- RealBasicVSR pre-clean stack, forward: lq = IterativeRefinement(lr) ----------------------
  * (vsr/models/RealBasicVSR/realbasicvsr.py:17-30): `steps` times x <- x + conv(ResidualBlock(x)) on
  * the F = n*t frames (F,3,h,w) fp32 planar.  params (4 + 4*blocks tensors): resblock.conv.0.{weight,
@@ -134,6 +147,15 @@ int vsr_flow_warp_bwd(int dtype, const void* dout_pm, const float* flow, float* 
 /* its backward w.r.t. the flow (grid_sampler_2d_backward's grid gradient): dflow (N,2,H,W) fp32   */
 int vsr_flow_warp_bwd_flow(int dtype, const void* in_pm, const void* dout_pm, const float* flow,
                            float* dflow, int N, int H, int W, int C, void* stream);
+
+/* the same three with grid_sample's padding_mode: 0 = 'zeros', 1 = 'border' (flow_warp(..., padding_mode='border'),
+ * spynet.py:60,95: clamped sample coordinates; a clamped coordinate has zero flow gradient)                        */
+int vsr_flow_warp_fwd_ex(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H, int W, int C,
+                         int padding_mode, void* stream);
+int vsr_flow_warp_bwd_ex(int dtype, const void* dout_pm, const float* flow, float* dacc_pm_f32, int N, int H, int W, int C,
+                         int padding_mode, void* stream);
+int vsr_flow_warp_bwd_flow_ex(int dtype, const void* in_pm, const void* dout_pm, const float* flow, float* dflow, int N,
+                              int H, int W, int C, int padding_mode, void* stream);
 
 /* layout converters between the reference's planar fp32 and pixel-major `dtype`              */
 int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int C,

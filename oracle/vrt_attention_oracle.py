@@ -106,3 +106,42 @@ def tmsa_forward(sd: Mapping[str, Tensor], x: Tensor, mask_matrix: Optional[Tens
     z = F.linear(F.gelu(F.linear(z, sd["mlp.fc11.weight"], sd["mlp.fc11.bias"])) * F.linear(z, sd["mlp.fc12.weight"], sd["mlp.fc12.bias"]),
                  sd["mlp.fc2.weight"], sd["mlp.fc2.bias"])          # Mlp_GEGLU, window_attention.py:79-98
     return x + z
+
+
+def vrt_spynet_forward(sd: Mapping[str, Tensor], ref: Tensor, supp: Tensor, return_levels=(5,)):
+    """SpyNet.forward / .process of the VRT tree (vsr/models/VRT/modules/spynet.py:98-157): the canonical SPyNet -- no ReLU
+    after a level's last conv (:68-82), keys basic_module.{l}.basic_module.{0,2,4,6,8} -- returning the flows of the
+    requested pyramid levels, finest first, each resized to (h // scale, w // scale) and rescaled (:134-141)."""
+    from .basicvsr_oracle import flow_warp
+    import math
+    h, w = ref.shape[2:]
+    w_floor = math.floor(math.ceil(w / 32.0) * 32.0)
+    h_floor = math.floor(math.ceil(h / 32.0) * 32.0)
+    ref = F.interpolate(ref, size=(h_floor, w_floor), mode="bilinear", align_corners=False)
+    supp = F.interpolate(supp, size=(h_floor, w_floor), mode="bilinear", align_corners=False)
+    refs, supps = [(ref - sd["mean"]) / sd["std"]], [(supp - sd["mean"]) / sd["std"]]
+    for _ in range(5):
+        refs.insert(0, F.avg_pool2d(refs[0], 2, 2, count_include_pad=False))
+        supps.insert(0, F.avg_pool2d(supps[0], 2, 2, count_include_pad=False))
+    flow = refs[0].new_zeros([refs[0].size(0), 2, refs[0].size(2) // 2, refs[0].size(3) // 2])
+    out = []
+    for level in range(6):
+        up = F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
+        if up.size(2) != refs[level].size(2):                      # :119-122 (only the all-zero level-0 flow ever needs it)
+            up = F.pad(up, [0, 0, 0, 1], mode="replicate")
+        if up.size(3) != refs[level].size(3):
+            up = F.pad(up, [0, 1, 0, 0], mode="replicate")
+        x = torch.cat([refs[level], flow_warp(supps[level], up, padding_mode="border"), up], 1)
+        for j in (0, 2, 4, 6, 8):
+            k = f"basic_module.{level}.basic_module.{j}."
+            x = F.conv2d(x, sd[k + "weight"], sd[k + "bias"], padding=3)
+            if j < 8:
+                x = F.relu(x)
+        flow = x + up
+        if level in return_levels:
+            scale = 2 ** (5 - level)
+            fo = F.interpolate(flow, size=(h // scale, w // scale), mode="bilinear", align_corners=False)
+            fo = fo * torch.tensor([float(w // scale) / float(w_floor // scale), float(h // scale) / float(h_floor // scale)],
+                                   dtype=fo.dtype).view(1, 2, 1, 1)
+            out.insert(0, fo)
+    return out

@@ -374,6 +374,23 @@ def vrt():
     store["t__keys"] = np.asarray(sorted(blk.state_dict().keys()))
     np.savez_compressed(os.path.join(HERE, "vrt_window_attention.npz"), **store)
     print("vrt_window_attention", len(store))
+    # the VRT tree's canonical SpyNet (conf/train/model/spynet.yaml: return_levels [2,3,4,5]); pretrained weights are absent
+    # (.MISSING_LARGE_BLOBS) -> keyed weights
+    from vsrlab.vsr.models.VRT.modules import spynet as ref_spy
+    net = ref_spy.SpyNet(pretrained=False, return_levels=[2, 3, 4, 5])
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            p.copy_(keyed_tensor(k, tuple(p.shape)) * (3.0 if k.endswith("weight") else 1.0))    # x3: flows of a few pixels
+    store = {"keys": np.asarray(sorted(net.state_dict().keys()))}
+    for tag, shape in (("a", (1, 3, 64, 96)), ("b", (2, 3, 40, 72))):
+        ref, supp = rand(80 + ord(tag), *shape), rand(90 + ord(tag), *shape)
+        with torch.no_grad():
+            flows = net(ref, supp)
+        for i, f in enumerate(flows):
+            store[f"{tag}__flow{i}"] = f.float().numpy()
+        store[f"{tag}__seed_ref"], store[f"{tag}__seed_supp"] = np.asarray(80 + ord(tag)), np.asarray(90 + ord(tag))
+    np.savez_compressed(os.path.join(HERE, "vrt_spynet.npz"), **store)
+    print("vrt_spynet", {k: v.shape for k, v in store.items()})
 
 
 if __name__ == "__main__":

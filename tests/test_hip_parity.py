@@ -85,6 +85,27 @@ def test_flow_warp_forward_backward_vs_oracle_and_golden(dtype):
         assert rel_err(out, g["zeros"]) < 1e-5                      # the reference's own output
 
 
+def test_flow_warp_border_mode_vs_oracle_and_golden():
+    """flow_warp(x, flow, padding_mode='border') (spynet.py:60,95): the reference's own output (golden), and the oracle's
+    gradients w.r.t. x and w.r.t. the flow (clamped coordinates carry no flow gradient), fp32 build."""
+    from vsrlab_amd import functional as VF
+    dev = _gpu()
+    g = golden("flow_warp")
+    x = rand(g["seed_x"], 2, 5, 9, 11, lo=-1, hi=1)
+    flow = rand(g["seed_flow"], 2, 2, 9, 11, lo=-8, hi=8)
+    cot = rand(23, 2, 5, 9, 11, lo=-1, hi=1)
+    xg = x.clone().to(dev).requires_grad_(True)
+    fg = flow.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    out = VF.flow_warp(xg, fg, padding_mode="border", compute_dtype="fp32")
+    out.backward(cot.to(dev))
+    xo, fo = x.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    ref = O.flow_warp(xo, fo, "border")
+    ref.backward(cot)
+    assert rel_err(out, g["border"]) < 1e-5 and rel_err(out, ref) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 1e-5
+    assert rel_err(fg.grad.permute(0, 3, 1, 2), fo.grad) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(1, 8, 32), (2, 13, 37), (1, 40, 72)])
 def test_conv3x3_c64_fwd_dgrad_wgrad(dtype, shape):
@@ -312,6 +333,35 @@ def test_spynet_parameter_gradients_vs_oracle():
     glob, worst, cos = _grad_report(grads, refg)
     assert glob < 1e-3, (glob, worst)
     assert worst[0] < 5e-3, worst
+
+
+def test_spynet_frame_gradients_vs_oracle():
+    """Spynet called alone, differentiated w.r.t. its two frames with FROZEN weights (what a caller composing its own
+    pipeline needs; inside BasicVSR the same code feeds the pre-clean stack): fp32 build against the fp64 oracle.  Weights
+    x 0.25 keep the flows small enough that fp32 rounding does not flip ReLU masks in the coarse-to-fine recursion."""
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.spynet import Spynet
+    dev = _gpu()
+    sd = {k: (v * 0.25 if k.endswith("weight") else v) for k, v in O.keyed_state_dict(O.spynet_param_shapes()).items()}
+    m = Spynet(False)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    ref, supp = rand(8, 1, 3, 40, 72), rand(9, 1, 3, 40, 72)
+    cot = rand(24, 1, 2, 40, 72, lo=-1, hi=1)
+    rg, sg = ref.clone().to(dev).requires_grad_(True), supp.clone().to(dev).requires_grad_(True)
+    os.environ["VSRLAB_AMD_DTYPE"] = "fp32"
+    try:
+        flow = m(rg, sg)
+        (flow * cot.to(dev)).sum().backward()
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]
+    ro, so = ref.double().requires_grad_(True), supp.double().requires_grad_(True)
+    fo = O.spynet_forward({k: v.double() for k, v in sd.items()}, ro, so)
+    (fo * cot.double()).sum().backward()
+    assert rel_err(flow, fo) < 1e-4
+    assert rel_l2(rg.grad, ro.grad) < 2e-3 and rel_l2(sg.grad, so.grad) < 2e-3
+    assert all(p.grad is None for p in m.parameters())
 
 
 def test_basicvsr_train_flow_vs_golden():

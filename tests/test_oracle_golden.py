@@ -308,3 +308,27 @@ def test_vrt_window_attention_and_tmsa_vs_reference():
     (y * cot).sum().backward()
     assert rel_err(y, g["t__out"]) < 1e-6 and rel_err(x.grad, g["t__dx"]) < 1e-6
     assert _vrt_check("t", g, {k: v.grad for k, v in leaves.items() if v.is_floating_point() and v.requires_grad}) == 17
+
+
+def _vrt_spynet_sd():
+    from vsrlab_amd.vsr.models.VRT.modules.spynet import SpyNet
+    m = SpyNet(False, [2, 3, 4, 5])
+    sd = {}
+    for k, v in m.state_dict().items():
+        sd[k] = v if k in ("mean", "std") else O.keyed_tensor(k, tuple(v.shape)) * (3.0 if k.endswith("weight") else 1.0)
+    return sd
+
+
+def test_vrt_spynet_multi_level_flows_vs_reference():
+    """The VRT tree's canonical SpyNet (no final ReLU, return_levels [2,3,4,5]) on a /32 frame and on one that is resized."""
+    from oracle import vrt_attention_oracle as V
+    g = golden("vrt_spynet")
+    sd = _vrt_spynet_sd()
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "vrt_spynet.npz"), allow_pickle=False) as z:
+        assert sorted(sd) == [str(k) for k in z["keys"]]
+    for tag, shape in (("a", (1, 3, 64, 96)), ("b", (2, 3, 40, 72))):
+        ref, supp = rand(int(g[f"{tag}__seed_ref"]), *shape), rand(int(g[f"{tag}__seed_supp"]), *shape)
+        flows = V.vrt_spynet_forward(sd, ref, supp, (2, 3, 4, 5))
+        assert len(flows) == 4
+        for i, f in enumerate(flows):
+            assert rel_err(f, g[f"{tag}__flow{i}"]) < TOL, (tag, i)

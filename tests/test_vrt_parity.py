@@ -169,3 +169,31 @@ def test_window_attention_config5_scale_properties():
     assert abs(float(dv[0, :, 0, 0].sum()) - N) < 0.05 * N
     # v is constant, so the scores do not influence the output: dq, dk and dbias vanish up to rounding
     assert float(dqkv[:, :, 0].float().abs().max()) < 5e-2 and float(dbias.abs().max()) < 0.5 * B / 100
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_vrt_spynet_multi_level_vs_golden(dtype):
+    """vsrlab.vsr.models.VRT.modules.spynet.SpyNet (conf/train/model/spynet.yaml: return_levels [2,3,4,5]) on the HIP SPyNet
+    engine without the final ReLU: the four flows against the reference's own outputs."""
+    dev = _gpu()
+    from vsrlab_amd.vsr.models.VRT.modules.spynet import SpyNet
+    g = golden("vrt_spynet")
+    m = SpyNet(False, [2, 3, 4, 5])
+    sd = {k: (v if k in ("mean", "std") else O.keyed_tensor(k, tuple(v.shape)) * (3.0 if k.endswith("weight") else 1.0))
+          for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    import os
+    os.environ["VSRLAB_AMD_DTYPE"] = dtype
+    try:
+        for tag, shape in (("a", (1, 3, 64, 96)), ("b", (2, 3, 40, 72))):
+            ref, supp = rand(int(g[f"{tag}__seed_ref"]), *shape).to(dev), rand(int(g[f"{tag}__seed_supp"]), *shape).to(dev)
+            with torch.no_grad():
+                flows = m(ref, supp)
+            assert len(flows) == 4
+            for i, f in enumerate(flows):
+                assert rel_err(f, g[f"{tag}__flow{i}"]) < (1e-3 if dtype == "fp32" else 6e-2), (tag, i, rel_err(f, g[f"{tag}__flow{i}"]))
+        with pytest.raises(NotImplementedError):
+            m(ref.requires_grad_(True), supp)                        # inference-only variant: loud
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]

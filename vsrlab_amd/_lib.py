@@ -43,12 +43,17 @@ _SIGNATURES = {
     "vsr_spynet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "vsr_spynet_forward": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "vsr_spynet_backward": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    "vsr_spynet_forward_ex": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_size_t, _P]),
+    "vsr_spynet_backward_ex": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "vsr_cleaner_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vsr_cleaner_forward": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_size_t, c_int, _P]),
     "vsr_cleaner_backward": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "vsr_flow_warp_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vsr_flow_warp_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vsr_flow_warp_bwd_flow": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vsr_flow_warp_fwd_ex": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vsr_flow_warp_bwd_ex": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vsr_flow_warp_bwd_flow_ex": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vsr_planar_to_pm": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vsr_pm_to_planar": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -43,7 +43,7 @@ __device__ __forceinline__ float warp_coord(float base, float flow, int dim) {
 // out[n,y,x,:] = bilinear(in[n], (x+fx, y+fy)), zeros padding (each out-of-image tap contributes 0).
 template <typename T>
 __global__ void warp_fwd_kernel(const T* __restrict__ in, const float* __restrict__ flow, T* __restrict__ out,
-                                int N, int H, int W, int C, long long flow_nstride) {
+                                int N, int H, int W, int C, long long flow_nstride, int border) {
     typedef typename EW<T>::chunk_t chunk_t;
     const int CP = C / 8;
     const long long total = (long long)N * H * W * CP;
@@ -54,8 +54,13 @@ __global__ void warp_fwd_kernel(const T* __restrict__ in, const float* __restric
         const int y = (int)((pix / W) % H);
         const int n = (int)(pix / ((long long)W * H));
         const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
-        const float px = warp_coord((float)x, fp[0], W);
-        const float py = warp_coord((float)y, fp[(long long)H * W], H);
+        float px = warp_coord((float)x, fp[0], W);
+        float py = warp_coord((float)y, fp[(long long)H * W], H);
+        // padding_mode='border' (grid_sample): the coordinate is clamped to the image; a clamped coordinate has no
+        // gradient w.r.t. the flow (ATen clip_coordinates_set_grad)
+        const bool in_x = !border || (px >= 0.f && px <= (float)(W - 1)), in_y = !border || (py >= 0.f && py <= (float)(H - 1));
+        if (border) { px = fminf(fmaxf(px, 0.f), (float)(W - 1)); py = fminf(fmaxf(py, 0.f), (float)(H - 1)); }
+        (void)in_x; (void)in_y;
         const float fx0 = floorf(px), fy0 = floorf(py);
         const int x0 = (int)fx0, y0 = (int)fy0;
         const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
@@ -85,7 +90,7 @@ __global__ void warp_fwd_kernel(const T* __restrict__ in, const float* __restric
 // bytes, the shape that runs at the full memory-side atomic rate on gfx950.
 template <typename T>
 __global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ flow, float* __restrict__ dacc,
-                                int N, int H, int W, int C, long long flow_nstride) {
+                                int N, int H, int W, int C, long long flow_nstride, int border) {
     const long long total = (long long)N * H * W * C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
@@ -94,8 +99,13 @@ __global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restr
         const int y = (int)((pix / W) % H);
         const int n = (int)(pix / ((long long)W * H));
         const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
-        const float px = warp_coord((float)x, fp[0], W);
-        const float py = warp_coord((float)y, fp[(long long)H * W], H);
+        float px = warp_coord((float)x, fp[0], W);
+        float py = warp_coord((float)y, fp[(long long)H * W], H);
+        // padding_mode='border' (grid_sample): the coordinate is clamped to the image; a clamped coordinate has no
+        // gradient w.r.t. the flow (ATen clip_coordinates_set_grad)
+        const bool in_x = !border || (px >= 0.f && px <= (float)(W - 1)), in_y = !border || (py >= 0.f && py <= (float)(H - 1));
+        if (border) { px = fminf(fmaxf(px, 0.f), (float)(W - 1)); py = fminf(fmaxf(py, 0.f), (float)(H - 1)); }
+        (void)in_x; (void)in_y;
         const float fx0 = floorf(px), fy0 = floorf(py);
         const int x0 = (int)fx0, y0 = (int)fy0;
         const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
@@ -299,7 +309,7 @@ __global__ void flow_out_kernel(const float* __restrict__ in, float* __restrict_
 // One thread per pixel, looping over the 8-channel chunks.
 template <typename T>
 __global__ void warp_bwd_flow_kernel(const T* __restrict__ in, const T* __restrict__ dout, const float* __restrict__ flow,
-                                     float* __restrict__ dflow, int N, int H, int W, int C, long long flow_nstride) {
+                                     float* __restrict__ dflow, int N, int H, int W, int C, long long flow_nstride, int border) {
     typedef typename EW<T>::chunk_t chunk_t;
     const int CP = C / 8;
     const long long total = (long long)N * H * W;
@@ -308,8 +318,13 @@ __global__ void warp_bwd_flow_kernel(const T* __restrict__ in, const T* __restri
         const int y = (int)((pix / W) % H);
         const int n = (int)(pix / ((long long)W * H));
         const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
-        const float px = warp_coord((float)x, fp[0], W);
-        const float py = warp_coord((float)y, fp[(long long)H * W], H);
+        float px = warp_coord((float)x, fp[0], W);
+        float py = warp_coord((float)y, fp[(long long)H * W], H);
+        // padding_mode='border' (grid_sample): the coordinate is clamped to the image; a clamped coordinate has no
+        // gradient w.r.t. the flow (ATen clip_coordinates_set_grad)
+        const bool in_x = !border || (px >= 0.f && px <= (float)(W - 1)), in_y = !border || (py >= 0.f && py <= (float)(H - 1));
+        if (border) { px = fminf(fmaxf(px, 0.f), (float)(W - 1)); py = fminf(fmaxf(py, 0.f), (float)(H - 1)); }
+        (void)in_x; (void)in_y;
         const float fx0 = floorf(px), fy0 = floorf(py);
         const int x0 = (int)fx0, y0 = (int)fy0;
         const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
@@ -336,8 +351,8 @@ __global__ void warp_bwd_flow_kernel(const T* __restrict__ in, const T* __restri
             }
         }
         float* dp = dflow + (long long)n * flow_nstride + (long long)y * W + x;
-        dp[0] = W > 1 ? gx : 0.f;
-        dp[(long long)H * W] = H > 1 ? gy : 0.f;
+        dp[0] = (W > 1 && in_x) ? gx : 0.f;
+        dp[(long long)H * W] = (H > 1 && in_y) ? gy : 0.f;
     }
 }
 
@@ -600,18 +615,18 @@ inline int grid_for(long long total, int block = 256) {
     else return VSR_ERR_BADARG;
 
 int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out, int N, int H, int W, int C,
-                        long long flow_nstride, hipStream_t st) {
+                        long long flow_nstride, hipStream_t st, int border) {
     if (C % 8) return VSR_ERR_BADARG;
     const long long total = (long long)N * H * W * (C / 8);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)in, flow, (T*)out, N, H, W, C, flow_nstride));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)in, flow, (T*)out, N, H, W, C, flow_nstride, border));
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
 
 int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
-                        long long flow_nstride, hipStream_t st) {
+                        long long flow_nstride, hipStream_t st, int border) {
     const long long total = (long long)N * H * W * C;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)dout, flow, dacc, N, H, W, C, flow_nstride));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)dout, flow, dacc, N, H, W, C, flow_nstride, border));
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
@@ -664,9 +679,9 @@ int vsr_launch_flow_out(const float* in, float* out, int P, int hu, int wu, int 
 }
 
 int vsr_launch_warp_bwd_flow(int dtype, const void* in, const void* dout, const float* flow, float* dflow, int N, int H, int W,
-                             int C, long long flow_nstride, hipStream_t st) {
+                             int C, long long flow_nstride, hipStream_t st, int border) {
     if (C % 8) return VSR_ERR_BADARG;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_flow_kernel<T>, dim3(grid_for((long long)N * H * W)), dim3(256), 0, st, (const T*)in, (const T*)dout, flow, dflow, N, H, W, C, flow_nstride));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_flow_kernel<T>, dim3(grid_for((long long)N * H * W)), dim3(256), 0, st, (const T*)in, (const T*)dout, flow, dflow, N, H, W, C, flow_nstride, border));
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

@@ -305,8 +305,11 @@ int spynet_pack(const Ctx& c, const SpyPlan& sp, const float* const* params, int
     return VSR_OK;
 }
 
+// last_relu: the reference's RealBasicVSR Spynet ends every level in a ReLU (spynet.py:16-18); the canonical SPyNet of
+// vsr/models/VRT/modules/spynet.py:76 does not.  level_out[l] (optional, l = 0..5): the level's flow resized to
+// (h >> (5-l), w >> (5-l)) like VRT's return_levels (VRT/modules/spynet.py:134-141).
 int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float* mean, const float* std, int n, int t,
-               int pair_mode, float* flows_out) {
+               int pair_mode, float* flows_out, bool last_relu = true, float* const* level_out = nullptr) {
     const int P = sp.P, F = sp.F, hu = sp.hu, wu = sp.wu;
     CK(vsr_launch_resize_norm(frames, (float*)c.at(sp.pyr[5]), mean, std, F, sp.h, sp.w, hu, wu, c.st));
     for (int l = 5; l > 0; --l)
@@ -322,7 +325,8 @@ int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float
         for (int j = 0; j < NSPY; ++j) {
             ConvArgs a = c.base(P, hl, wl);
             a.src[0] = c.at(bufs[j]); a.src_nstride[0] = pm_image_elems(hl, wl, SPY_CIP[j]);
-            a.wpack = c.at(sp.wpack[l][j]); a.bias = c.fat(sp.bias[l][j]); a.act = ACT_RELU;   // ReLU after the LAST conv too (spynet.py:16-18)
+            a.wpack = c.at(sp.wpack[l][j]); a.bias = c.fat(sp.bias[l][j]);
+            a.act = (j < NSPY - 1 || last_relu) ? ACT_RELU : ACT_NONE;     // RealBasicVSR's Spynet: ReLU after the LAST conv too (spynet.py:16-18)
             a.cout_real = SPY_CO[j];
             if (j < NSPY - 1) {
                 a.dst[0] = c.at(bufs[j + 1]); a.CD = SPY_CD[j]; a.dst_nstride = pm_image_elems(hl, wl, SPY_CD[j]);
@@ -336,8 +340,11 @@ int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float
                 CK(vsr_launch_add_f32(c.fat(fup), c.fat(sp.sres[l]), (float*)c.at(fcur), (long long)P * 2 * hl * wl, c.st));
             }
         }
+        if (level_out && level_out[l])
+            CK(vsr_launch_flow_out(c.fat(fcur), level_out[l], P, hl, wl, sp.h >> (5 - l), sp.w >> (5 - l), c.st));
         size_t tmp = fprev; fprev = fcur; fcur = tmp;
     }
+    if (!flows_out) return VSR_OK;
     return vsr_launch_flow_out(c.fat(fprev), flows_out, P, hu, wu, sp.h, sp.w, c.st);
 }
 
@@ -836,7 +843,7 @@ int vsr_basicvsr_get_flows(const VsrBasicVSRDesc* d, const void* workspace, floa
 }
 
 // ---- SPyNet alone ---------------------------------------------------------------------------------
-struct SpyAlone { SpyPlan sp; size_t frames, slab; size_t total; };
+struct SpyAlone { SpyPlan sp; size_t frames, slab, dframes; size_t total; };
 static SpyAlone spy_alone_plan(int N, int h, int w, int dtype, bool save) {
     SpyAlone s; Bump b;
     s.frames = b.take((size_t)2 * N * 3 * h * w * 4);
@@ -847,6 +854,7 @@ static SpyAlone spy_alone_plan(int N, int h, int w, int dtype, bool save) {
         int cp, xp, stride;
         vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
         s.slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+        s.dframes = b.take((size_t)2 * N * 3 * h * w * 4);
     }
     s.total = b.off;
     return s;
@@ -873,6 +881,26 @@ int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* param
     return spynet_run(c, s.sp, c.fat(s.frames), params[60], params[61], N, 2, 1, flow);
 }
 
+/* SPyNet with the options of the reference's OTHER SpyNet classes: last_relu = 0 is the canonical network
+ * (vsr/models/VRT/modules/spynet.py:68-157); level_out: HOST array of 6 device pointers (NULL entries = not wanted), level l
+ * receives the flow of pyramid level l resized to (h >> (5-l), w >> (5-l)) (its `return_levels`).  Forward only.       */
+int vsr_spynet_forward_ex(int N, int h, int w, int dtype, const float* const* params, int nparams, const float* ref,
+                          const float* supp, int last_relu, float* const* level_out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    if (N < 1 || h < 32 || w < 32 || !params || nparams != 62 || !ref || !supp || !level_out || !workspace) return VSR_ERR_BADARG;
+    if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+    const SpyAlone s = spy_alone_plan(N, h, w, dtype, false);
+    if (workspace_bytes < s.total) return VSR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Plan dummy; dummy.es = esize(dtype);
+    const Ctx c{dummy, (char*)workspace, st, dtype};
+    const size_t fb = (size_t)N * 3 * h * w * 4;
+    HIP_CHECK_RET(hipMemcpyAsync(c.at(s.frames), ref, fb, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK_RET(hipMemcpyAsync((char*)c.at(s.frames) + fb, supp, fb, hipMemcpyDeviceToDevice, st));
+    CK(spynet_pack(c, s.sp, params, 0));
+    return spynet_run(c, s.sp, c.fat(s.frames), params[60], params[61], N, 2, 1, nullptr, last_relu != 0, level_out);
+}
+
 int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int nparams, const float* dflow, void* workspace,
                         size_t workspace_bytes, void* stream) {
     if (N < 1 || h < 1 || w < 1 || !grads || nparams != 62 || !dflow || !workspace) return VSR_ERR_BADARG;
@@ -883,6 +911,27 @@ int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int
     Plan dummy; dummy.es = esize(dtype); dummy.slab[0] = dummy.slab[1] = s.slab;
     const Ctx c{dummy, (char*)workspace, (hipStream_t)stream, dtype};
     return spynet_backward(c, s.sp, dflow, N, 2, 1, grads, 0);
+}
+
+/* the same, plus the gradient w.r.t. the two input frames: dref, dsupp (N,3,h,w) fp32 are WRITTEN (either may be NULL).
+ * params: the 62 tensors of the forward (std is needed for the normalisation's adjoint); grads may be NULL (frozen net). */
+int vsr_spynet_backward_ex(int N, int h, int w, int dtype, const float* const* params, float* const* grads, int nparams, const float* dflow,
+                           float* dref, float* dsupp, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 1 || h < 1 || w < 1 || !params || nparams != 62 || !dflow || !workspace || !params[61]) return VSR_ERR_BADARG;
+    if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
+    if (grads) for (int k = 0; k < 60; k += 2) if (!grads[k] && grads[k + 1]) return VSR_ERR_BADARG;
+    const SpyAlone s = spy_alone_plan(N, h, w, dtype, true);
+    if (workspace_bytes < s.total) return VSR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Plan dummy; dummy.es = esize(dtype); dummy.slab[0] = dummy.slab[1] = s.slab;
+    const Ctx c{dummy, (char*)workspace, st, dtype};
+    const bool want = dref || dsupp;
+    const size_t fb = (size_t)N * 3 * h * w * 4;
+    if (want) HIP_CHECK_RET(hipMemsetAsync(c.at(s.dframes), 0, 2 * fb, st));
+    CK(spynet_backward(c, s.sp, dflow, N, 2, 1, grads, 0, want ? (float*)c.at(s.dframes) : nullptr, params[61]));
+    if (dref) HIP_CHECK_RET(hipMemcpyAsync(dref, c.at(s.dframes), fb, hipMemcpyDeviceToDevice, st));
+    if (dsupp) HIP_CHECK_RET(hipMemcpyAsync(dsupp, (char*)c.at(s.dframes) + fb, fb, hipMemcpyDeviceToDevice, st));
+    return VSR_OK;
 }
 
 // ---- RealBasicVSR pre-clean stack, forward (realbasicvsr.py:17-30) ------------------------------------
@@ -1071,6 +1120,22 @@ int vsr_flow_warp_bwd_flow(int dtype, const void* in_pm, const void* dout_pm, co
                            int Cc, void* stream) {
     if (bad_dtype(dtype) || !in_pm || !dout_pm || !flow || !dflow || bad_dims(N, H, W) || Cc < 16 || (Cc & 15)) return VSR_ERR_BADARG;
     return vsr_launch_warp_bwd_flow(dtype, in_pm, dout_pm, flow, dflow, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream);
+}
+/* padding_mode: 0 = 'zeros' (the propagation warps), 1 = 'border' (the warps inside SPyNet, spynet.py:60) */
+int vsr_flow_warp_fwd_ex(int dtype, const void* in_pm, const float* flow, void* out_pm, int N, int H, int W, int Cc, int padding_mode,
+                         void* stream) {
+    if (bad_dtype(dtype) || !in_pm || !flow || !out_pm || bad_dims(N, H, W) || Cc < 16 || (Cc & 15) || (padding_mode & ~1)) return VSR_ERR_BADARG;
+    return vsr_launch_warp_fwd(dtype, in_pm, flow, out_pm, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream, padding_mode);
+}
+int vsr_flow_warp_bwd_ex(int dtype, const void* dout_pm, const float* flow, float* dacc, int N, int H, int W, int Cc, int padding_mode,
+                         void* stream) {
+    if (bad_dtype(dtype) || !dout_pm || !flow || !dacc || bad_dims(N, H, W) || Cc < 16 || (Cc & 15) || (padding_mode & ~1)) return VSR_ERR_BADARG;
+    return vsr_launch_warp_bwd(dtype, dout_pm, flow, dacc, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream, padding_mode);
+}
+int vsr_flow_warp_bwd_flow_ex(int dtype, const void* in_pm, const void* dout_pm, const float* flow, float* dflow, int N, int H, int W,
+                              int Cc, int padding_mode, void* stream) {
+    if (bad_dtype(dtype) || !in_pm || !dout_pm || !flow || !dflow || bad_dims(N, H, W) || Cc < 16 || (Cc & 15) || (padding_mode & ~1)) return VSR_ERR_BADARG;
+    return vsr_launch_warp_bwd_flow(dtype, in_pm, dout_pm, flow, dflow, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream, padding_mode);
 }
 int vsr_planar_to_pm(int dtype, const float* in, void* out_pm, int N, int Cin, int H, int W, int Cc, void* stream) {
     if (bad_dtype(dtype) || !in || !out_pm || bad_dims(N, H, W) || Cin < 1 || Cc < Cin || (Cc & 15)) return VSR_ERR_BADARG;

@@ -9,10 +9,11 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
                      int* nslabs, hipStream_t st);      // *nslabs: partial slabs written (what the reduction sums)
 int vsr_launch_wgrad_reduce(const float* slab, int nwg, int ks, int cx, int cout, int cout_real, int cin_real, float* gw,
                             int I_total, int i_off, int o_mul, int o_add, float* gb, int accumulate, hipStream_t st);
+// border != 0: grid_sample padding_mode='border' (clamped coordinates) instead of 'zeros'
 int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out, int N, int H, int W, int C,
-                        long long flow_nstride, hipStream_t st);
+                        long long flow_nstride, hipStream_t st, int border = 0);
 int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
-                        long long flow_nstride, hipStream_t st);
+                        long long flow_nstride, hipStream_t st, int border = 0);
 int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, int N, int H, int W, int C, hipStream_t st);
 int vsr_launch_planar_to_pm(int dtype, const float* in, void* out, int N, int Cin, int H, int W, int C, hipStream_t st);
 int vsr_launch_pm_to_planar(int dtype, const void* in, float* out, int N, int Cout, int H, int W, int C, hipStream_t st);
@@ -23,7 +24,7 @@ int vsr_launch_spynet_prepare(int dtype, const float* frames, const float* flow_
                               int t, int P, int pair_mode, int h, int w, int level0, hipStream_t st);
 int vsr_launch_flow_out(const float* in, float* out, int P, int hu, int wu, int h, int w, hipStream_t st);
 int vsr_launch_warp_bwd_flow(int dtype, const void* in, const void* dout, const float* flow, float* dflow, int N, int H, int W,
-                             int C, long long flow_nstride, hipStream_t st);
+                             int C, long long flow_nstride, hipStream_t st, int border = 0);
 int vsr_launch_spynet_dres(int dtype, const float* dflow, const float* res, void* out, int P, int h, int w, hipStream_t st);
 int vsr_launch_spynet_prepare_bwd(int dtype, const void* dx16, const float* dflow_l, const float* frames, const float* flow_up,
                                   float* dflow_prev, float* dframes, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st);

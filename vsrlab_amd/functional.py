@@ -103,46 +103,46 @@ def from_pixel_major(x: torch.Tensor, channels: Optional[int] = None) -> torch.T
 # --------------------------------------------------------------------------------------------- #
 class _FlowWarpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, flow_planar, dtype):
+    def forward(ctx, x, flow_planar, dtype, border=0):
         n, c, h, w = x.shape
         lib = _lib.load()
         xin = to_pixel_major(x, dtype)
         cp = _pm_dims(xin)[3]
         out = _pm_like(xin)
         flow_planar = _f32c(flow_planar)
-        _lib.check(lib.vsr_flow_warp_fwd(dtype, _ptr(xin), _ptr(flow_planar), _ptr(out), n, h, w, cp, _stream()), "flow_warp_fwd")
+        _lib.check(lib.vsr_flow_warp_fwd_ex(dtype, _ptr(xin), _ptr(flow_planar), _ptr(out), n, h, w, cp, border, _stream()), "flow_warp_fwd")
         ctx.save_for_backward(flow_planar, xin if ctx.needs_input_grad[1] else None)
-        ctx.meta = (dtype, c, cp)
+        ctx.meta = (dtype, c, cp, border)
         return from_pixel_major(out, c)
 
     @staticmethod
     def backward(ctx, gout):
         flow_planar, xin = ctx.saved_tensors
-        dtype, c, cp = ctx.meta
+        dtype, c, cp, border = ctx.meta
         n, _, h, w = gout.shape
         lib = _lib.load()
         g = to_pixel_major(gout, dtype, cp)
         gx = gflow = None
         if ctx.needs_input_grad[0]:
             acc = torch.zeros((n, h, w, cp), dtype=torch.float32, device=gout.device)  # plain [N][H][W][C] fp32 accumulator
-            _lib.check(lib.vsr_flow_warp_bwd(dtype, _ptr(g), _ptr(flow_planar), _ptr(acc), n, h, w, cp, _stream()), "flow_warp_bwd")
+            _lib.check(lib.vsr_flow_warp_bwd_ex(dtype, _ptr(g), _ptr(flow_planar), _ptr(acc), n, h, w, cp, border, _stream()), "flow_warp_bwd")
             gx = acc[..., :c].permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[1]:
             gflow = torch.empty((n, 2, h, w), dtype=torch.float32, device=gout.device)
-            _lib.check(lib.vsr_flow_warp_bwd_flow(dtype, _ptr(xin), _ptr(g), _ptr(flow_planar), _ptr(gflow), n, h, w, cp, _stream()),
+            _lib.check(lib.vsr_flow_warp_bwd_flow_ex(dtype, _ptr(xin), _ptr(g), _ptr(flow_planar), _ptr(gflow), n, h, w, cp, border, _stream()),
                        "flow_warp_bwd_flow")
-        return gx, gflow, None
+        return gx, gflow, None, None
 
 
 def flow_warp(x: torch.Tensor, flow: torch.Tensor, interpolation: str = "bilinear", padding_mode: str = "zeros",
               align_corners: bool = True, compute_dtype: Optional[str] = None) -> torch.Tensor:
     """Drop-in for the reference ``flow_warp(x, flow)``: ``flow`` is channels-last (N,H,W,2),
     [...,0] = horizontal displacement in pixels.  Differentiable w.r.t. ``x`` and ``flow``."""
-    if interpolation != "bilinear" or padding_mode != "zeros" or not align_corners:
-        raise NotImplementedError("HIP flow_warp implements the BasicVSR propagation case: bilinear, zeros padding, "
-                                  "align_corners=True (border padding is fused inside the SPyNet kernels)")
+    if interpolation != "bilinear" or padding_mode not in ("zeros", "border") or not align_corners:
+        raise NotImplementedError("HIP flow_warp implements the reference's two uses: bilinear, align_corners=True, padding "
+                                  "'zeros' (propagation, basicvsr.py:55,70) or 'border' (SPyNet, spynet.py:60)")
     _require_gpu(x, flow)
-    return _FlowWarpFn.apply(x, flow.permute(0, 3, 1, 2), resolve_dtype(compute_dtype))
+    return _FlowWarpFn.apply(x, flow.permute(0, 3, 1, 2), resolve_dtype(compute_dtype), 1 if padding_mode == "border" else 0)
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -222,7 +222,8 @@ def residual_conv(x, w1, b1, w2, b2, compute_dtype: Optional[str] = None):
 # SPyNet forward (reference: vsr/models/RealBasicVSR/modules/spynet.py:69-93)
 # --------------------------------------------------------------------------------------------- #
 class _SpynetFn(torch.autograd.Function):
-    """flow = Spynet(ref, supp) with the parameter gradients on the HIP engine (ref / supp are not differentiated)."""
+    """flow = Spynet(ref, supp) with its backward on the HIP engine: parameter gradients (train_flow) and the gradient
+    w.r.t. the two frames (border warps, image pyramid, /32 resize, normalisation)."""
 
     @staticmethod
     def forward(ctx, ref, supp, dtype, need_bwd, *params):
@@ -243,26 +244,53 @@ class _SpynetFn(torch.autograd.Function):
         n, h, w, dtype, need_bwd = ctx.meta
         if not need_bwd:
             raise RuntimeError("vsrlab_amd: backward through a SPyNet forward that ran without need_backward")
+        if ctx.ws is None:
+            raise RuntimeError("vsrlab_amd: trying to backward through the SPyNet graph a second time")
         lib = _lib.load()
-        grads = [torch.zeros_like(p) if k < 60 else None for k, p in enumerate(ctx.ps)]
-        _lib.check(lib.vsr_spynet_backward(n, h, w, dtype, _ptr_array(grads), len(grads), _ptr(_f32c(dflow)), _ptr(ctx.ws),
-                                           ctx.ws.numel(), _stream()), "spynet_backward")
+        want_p = any(ctx.needs_input_grad[4 + k] for k in range(60))
+        grads = [torch.zeros_like(p) if (k < 60 and want_p) else None for k, p in enumerate(ctx.ps)]
+        dref = torch.empty((n, 3, h, w), dtype=torch.float32, device=dflow.device) if ctx.needs_input_grad[0] else None
+        dsupp = torch.empty((n, 3, h, w), dtype=torch.float32, device=dflow.device) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.vsr_spynet_backward_ex(n, h, w, dtype, _ptr_array(ctx.ps), _ptr_array(grads) if want_p else None, len(grads),
+                                              _ptr(_f32c(dflow)), _ptr(dref), _ptr(dsupp), _ptr(ctx.ws), ctx.ws.numel(), _stream()),
+                   "spynet_backward")
         ctx.ws = None
-        return (None, None, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + k]) else None
-                                                for k, g in enumerate(grads))
+        return (dref, dsupp, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + k]) else None
+                                                 for k, g in enumerate(grads))
 
 
 def spynet_flow(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.Tensor,
                 compute_dtype: Optional[str] = None) -> torch.Tensor:
     """``params``: the 62 Spynet tensors in state_dict order (60 conv tensors, mean, std).  Differentiable w.r.t. the
-    60 conv tensors (train_flow, basicvsr.py:25-28); not w.r.t. the frames."""
+    60 conv tensors (train_flow, basicvsr.py:25-28) and w.r.t. both frames."""
     _require_gpu(ref, supp)
     if len(params) != 62:
         raise ValueError("expected the 62 tensors of Spynet.state_dict()")
-    if torch.is_grad_enabled() and (ref.requires_grad or supp.requires_grad):
-        raise NotImplementedError("gradient of SPyNet w.r.t. its input frames is not on the HIP path yet")
-    need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params[:60])
+    need_bwd = torch.is_grad_enabled() and (ref.requires_grad or supp.requires_grad or any(p.requires_grad for p in params[:60]))
     return _SpynetFn.apply(ref, supp, resolve_dtype(compute_dtype), need_bwd, *params)
+
+
+def spynet_levels(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.Tensor, return_levels: Sequence[int],
+                  last_relu: bool = False, compute_dtype: Optional[str] = None) -> List[torch.Tensor]:
+    """Forward of the canonical SPyNet (vsr/models/VRT/modules/spynet.py:68-157): the flows of the requested pyramid
+    levels (5 = full resolution, 4 = 1/2, ...), finest first, like the reference's ``flow_list``.  Inference only."""
+    _require_gpu(ref, supp)
+    if torch.is_grad_enabled() and (ref.requires_grad or supp.requires_grad or any(p.requires_grad for p in params[:60])):
+        raise NotImplementedError("the multi-level SPyNet forward is inference-only on the HIP path: call it under torch.no_grad() "
+                                  "or freeze it (the BasicVSR path's Spynet is the differentiable one)")
+    n, _, h, w = ref.shape
+    lib = _lib.load()
+    dtype = resolve_dtype(compute_dtype)
+    ps = [_f32c(p) for p in params]
+    ws = torch.empty(lib.vsr_spynet_workspace_bytes(n, h, w, dtype, 0), dtype=torch.uint8, device=ref.device)
+    outs: List[Optional[torch.Tensor]] = [None] * 6
+    for lv in set(int(v) for v in return_levels):
+        if not 0 <= lv <= 5:
+            raise ValueError("return_levels are pyramid levels 0..5")
+        outs[lv] = torch.empty((n, 2, h >> (5 - lv), w >> (5 - lv)), dtype=torch.float32, device=ref.device)
+    _lib.check(lib.vsr_spynet_forward_ex(n, h, w, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(ref)), _ptr(_f32c(supp)), int(last_relu),
+                                         _ptr_array(outs), _ptr(ws), ws.numel(), _stream()), "spynet_forward_ex")
+    return [outs[lv] for lv in sorted(set(int(v) for v in return_levels), reverse=True)]
 
 
 # --------------------------------------------------------------------------------------------- #
