@@ -174,6 +174,16 @@ int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float
 int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm,
                           const void* res_pm, const void* aux_pm, int mask_mode, int N, int H,
                           int W, void* stream);
+/* One convolution layer, forward only, for the building blocks the reference's modules expose on their own: ConvReLU
+ * (core/modules/conv.py:15-22), SpynetModule (spynet.py:13-21), PixelShufflePack (upsampling.py:4-12), the stem of
+ * ResidualBlock (conv.py:97).  w fp32 OIHW, b fp32 or NULL.
+ *   ks 3 / 1: 64 -> 64 (pixel_shuffle != 0: 64 -> 256 written as (N,2H,2W,64));
+ *   ks 7    : (cin_pm, cout_real) in {(16,32), (32,64), (64,32), (32,16), (16,2: y_planar)} with cin_real = 8,32,64,32,16;
+ *   lr_planar (N,3,H,W), ks 3: the conv reads cat([lr, x_pm]) (cin_real 67) or lr alone (x_pm NULL, cin_real 3).
+ * y_pm: cd channels per pixel; y_planar (N,cout_real,H,W) for cout_real <= 4.  wpack: scratch, 49*64*64*4 elements.   */
+int vsr_conv_layer_fwd(int dtype, int ks, const void* x_pm, int cin_pm, const float* lr_planar, const float* w,
+                       const float* b, int cin_real, int cout_real, void* wpack, void* y_pm, int cd, float* y_planar,
+                       int act, float slope, int pixel_shuffle, int N, int H, int W, void* stream);
 /* gw (64,64,3,3) and gb (64) fp32, overwritten.  slab: fp32 scratch of
  * vsr_conv3x3_c64_wgrad_slab_floats() floats.                                                */
 size_t vsr_conv3x3_c64_wgrad_slab_floats(void);

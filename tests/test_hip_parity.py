@@ -743,3 +743,52 @@ def test_long_clip_more_than_8_frames_fp32():
     assert rel_err(sr, sr_o) < 1e-3
     glob, worst, cos = _grad_report(grads, grads_o)
     assert glob < 2e-3 and worst[0] < 2e-2, (glob, worst)
+
+
+def test_standalone_module_forwards_vs_oracle():
+    """The reference's building blocks called on their own (inference): ResidualBlock on cat([lr, feat]) (67 channels: the
+    trunks) and on lr alone (3 channels: the pre-clean stack), PixelShufflePack, ConvReLU and SpynetModule, fp32 build
+    against the oracle's restatements (pinned to the reference at 16 channels by tests/test_oracle_golden.py); under
+    autograd they refuse instead of silently producing no gradient."""
+    dev = _gpu()
+    from vsrlab_amd.core.modules.conv import ConvReLU, ResidualBlock
+    from vsrlab_amd.core.modules.upsampling import PixelShufflePack
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.spynet import SpynetModule
+    os.environ["VSRLAB_AMD_DTYPE"] = "fp32"
+    try:
+        for cin in (67, 3):
+            m = ResidualBlock(cin, 64, 2)
+            sd = O.keyed_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+            m.load_state_dict(sd, strict=True)
+            x = rand(61 + cin, 2, cin, 13, 37, lo=-1, hi=1)
+            with torch.no_grad():
+                y = m.to(dev)(x.to(dev))
+            assert rel_err(y, O.residual_block(sd, "", x, 2)) < 1e-3, cin
+        with pytest.raises(NotImplementedError):
+            m(x.to(dev).requires_grad_(True))
+        p = PixelShufflePack(64, 64, 2)
+        sd = O.keyed_state_dict({k: tuple(v.shape) for k, v in p.state_dict().items()})
+        p.load_state_dict(sd, strict=True)
+        x = rand(62, 2, 64, 7, 9, lo=-1, hi=1)
+        with torch.no_grad():
+            y = p.to(dev)(x.to(dev))
+        assert tuple(y.shape) == (2, 64, 14, 18) and rel_err(y, O.pixel_shuffle_pack(sd, "", x)) < 1e-3
+        c = ConvReLU(32, 64, 7, 1, 3)
+        sd = O.keyed_state_dict({k: tuple(v.shape) for k, v in c.state_dict().items()})
+        c.load_state_dict(sd, strict=True)
+        x = rand(63, 1, 32, 20, 41, lo=-1, hi=1)
+        with torch.no_grad():
+            y = c.to(dev)(x.to(dev))
+        assert rel_err(y, F.relu(F.conv2d(x, sd["conv.0.weight"], sd["conv.0.bias"], padding=3))) < 1e-3
+        s = SpynetModule()
+        sd = O.keyed_state_dict({k: tuple(v.shape) for k, v in s.state_dict().items()})
+        s.load_state_dict(sd, strict=True)
+        x = rand(64, 2, 8, 24, 40, lo=-1, hi=1)
+        with torch.no_grad():
+            y = s.to(dev)(x.to(dev))
+        ref = x
+        for j in range(5):
+            ref = F.relu(F.conv2d(ref, sd[f"basic_module.{j}.conv.0.weight"], sd[f"basic_module.{j}.conv.0.bias"], padding=3))
+        assert tuple(y.shape) == (2, 2, 24, 40) and rel_err(y, ref) < 1e-3
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]

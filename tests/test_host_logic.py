@@ -109,8 +109,17 @@ def test_hydra_target_alias_and_instantiate():
                                     "mid_channels": 64, "upscale": 4, "res_blocks": 1, "pretrained_flow": False,
                                     "train_flow": False})               # conf/train/model/basicvsr.yaml keys
         assert type(m).__module__ == "vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr"
-        sp = vsrlab_amd.instantiate({"_target_": "vsrlab.optical_flow.models.spynet.SpyNet"})
-        assert len(sp.state_dict()) == 62
+        sp = vsrlab_amd.instantiate({"_target_": "vsrlab.optical_flow.models.spynet.SpyNet", "k": 6})
+        assert len(sp.state_dict()) == 60 and "units.0.module.0.weight" in sp.state_dict()   # optical_flow/models/spynet/model.py:9-80 keys
+        vs = vsrlab_amd.instantiate({"_target_": "vsrlab.vsr.models.VRT.modules.spynet.SpyNet", "pretrained": False,
+                                     "return_levels": [2, 3, 4, 5]})                          # conf/train/model/spynet.yaml
+        assert len(vs.state_dict()) == 62 and "basic_module.0.basic_module.8.weight" in vs.state_dict()
+        import importlib
+        dmod = importlib.import_module("vsrlab.vsr.models.RealBasicVSR.modules.unet-discriminator")   # conf/train/gan.yaml:17
+        d = dmod.UNetDiscriminator(in_ch=3, mid_ch=64)
+        assert "conv_3.conv.weight_orig" in d.state_dict() and "conv_3.conv.weight_u" in d.state_dict()
+        wa = importlib.import_module("vsrlab.vsr.models.VRT.modules.window_attention")
+        assert hasattr(wa, "WindowAttention") and hasattr(wa, "compute_mask")
     finally:
         for k in [k for k in sys.modules if k == "vsrlab" or k.startswith("vsrlab.")]:
             del sys.modules[k]

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "vsr_pm_to_planar": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_dgrad": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vsr_conv_layer_fwd": (c_int, [c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_wgrad_slab_floats": (c_size_t, []),
     "vsr_conv3x3_c64_wgrad": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vsr_charbonnier_fwd_bwd": (c_int, [_P, _P, _P, _P, c_longlong, c_float, _P]),

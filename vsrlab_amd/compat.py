@@ -17,7 +17,9 @@ def install_as_vsrlab(force: bool = False) -> None:
     for sub in ("core", "core.modules", "core.modules.conv", "core.modules.upsampling", "core.losses", "vsr", "vsr.models",
                 "vsr.models.RealBasicVSR", "vsr.models.RealBasicVSR.realbasicvsr", "vsr.models.RealBasicVSR.modules",
                 "vsr.models.RealBasicVSR.modules.basicvsr", "vsr.models.RealBasicVSR.modules.spynet",
-                "vsr.models.RealBasicVSR.modules.unet-discriminator", "core.utils", "train_gan", "optical_flow",
+                "vsr.models.RealBasicVSR.modules.unet-discriminator", "vsr.models.VRT", "vsr.models.VRT.modules",
+                "vsr.models.VRT.modules.spynet", "vsr.models.VRT.modules.window_attention", "vsr.models.VRT.modules.tmsa",
+                "core.utils", "train_gan", "optical_flow",
                 "optical_flow.models", "optical_flow.models.spynet"):
         sys.modules["vsrlab." + sub] = importlib.import_module("vsrlab_amd." + sub)
 

@@ -1,8 +1,9 @@
 """Shared conv blocks of the hot path, HIP-backed.  Mirrors vsrlab ``src/core/modules/conv.py``:
 ``ConvReLU`` (:15-22), ``ResidualConv`` (:82-92), ``ResidualBlock`` (:94-103) -- same constructor
 arguments, same parameter names (``conv.0.weight``, ``res_block.{i}.conv1.weight`` ...), so
-checkpoints load strictly.  The modules are parameter containers: inside ``BasicVSR`` the whole
-propagation runs in one engine call; called on their own they dispatch to the per-op kernels."""
+checkpoints load strictly.  Inside ``BasicVSR`` / ``Spynet`` / ``UNetDiscriminator`` the whole network runs in one engine
+call and these modules are its parameter containers; called on their own they dispatch to the per-layer kernels
+(``ResidualConv`` with its full backward; ``ConvReLU`` / ``ResidualBlock`` forward-only, i.e. under ``torch.no_grad()``)."""
 import torch
 import torch.nn as nn
 
@@ -48,7 +49,10 @@ class ConvReLU(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_ch, out_ch, *args, **kwargs), nn.ReLU())
 
     def forward(self, x):
-        raise NotImplementedError("ConvReLU is fused into the SPyNet engine; call Spynet(ref, supp)")
+        conv = self.conv[0]
+        if conv.stride != (1, 1) or conv.padding != (conv.kernel_size[0] // 2,) * 2:
+            raise NotImplementedError("HIP ConvReLU: stride 1, 'same' padding")
+        return VF.conv_relu_forward(x, conv.weight, conv.bias)
 
 
 class ResidualConv(nn.Module):
@@ -73,5 +77,5 @@ class ResidualBlock(nn.Module):
         self.res_block = nn.Sequential(*[ResidualConv(out_ch) for _ in range(blocks)])
 
     def forward(self, x):
-        raise NotImplementedError("ResidualBlock runs inside the BasicVSR engine (stem conv on cat(lr, feat) is fused "
-                                  "with the propagation); standalone use is not on the HIP path yet")
+        blocks = [(b.conv1.weight, b.conv1.bias, b.conv2.weight, b.conv2.bias) for b in self.res_block]
+        return VF.residual_block_forward(x, self.conv[0].weight, self.conv[0].bias, blocks)

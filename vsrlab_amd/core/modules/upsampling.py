@@ -1,7 +1,10 @@
 """``PixelShufflePack`` (vsrlab ``src/core/modules/upsampling.py:4-12``): conv3x3 C->4C then
 PixelShuffle(2), no activation.  On the HIP path the shuffle is the store pattern of the conv
-kernel (four sub-convolutions, one launch); this module holds the parameters."""
+kernel (four sub-convolutions, one launch).  Inside ``BasicVSR`` it runs in the engine; called on its own it is one
+``vsr_conv_layer_fwd`` launch (forward-only)."""
 import torch.nn as nn
+
+from ... import functional as VF
 
 
 class PixelShufflePack(nn.Module):
@@ -11,4 +14,4 @@ class PixelShufflePack(nn.Module):
         self.pixel_shuffle = nn.PixelShuffle(upscale_factor)
 
     def forward(self, x):
-        raise NotImplementedError("PixelShufflePack runs inside the BasicVSR engine; standalone use is not on the HIP path yet")
+        return VF.pixel_shuffle_pack_forward(x, self.upconv.weight, self.upconv.bias)

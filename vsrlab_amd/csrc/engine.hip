@@ -1176,6 +1176,81 @@ int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wp
     return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
 }
 
+/* One convolution layer on blocked pixel-major tensors, forward only: the building blocks the reference's modules expose
+ * on their own (ConvReLU core/modules/conv.py:15-22, SpynetModule spynet.py:13-21, PixelShufflePack upsampling.py:4-12,
+ * the stem of ResidualBlock conv.py:97).  w: fp32 OIHW (cout_real, cin_real [+3 for lr_planar], ks, ks); b: cout_real or NULL.
+ *   ks 3 or 1: x_pm has 64 channels, 64 outputs (pixel_shuffle: 256 outputs written as (N,2H,2W,64), upsampling.py:10-12);
+ *   ks 7: (cin_pm, cout) in {(16,32), (32,64), (64,32), (32,16), (16,2 -> y_planar)} (the SPyNet layers);
+ *   lr_planar (N,3,H,W) fp32, ks 3: the conv reads cat([lr, x]) (x_pm may be NULL = lr only): the trunk / pre-clean stems.
+ * y_pm has cd channels per pixel (16 / 32 / 64); y_planar (N,cout_real,H,W) fp32 instead when cout_real <= 4.
+ * wpack: scratch of 49 * 64 * 64 * 4 elements of `dtype` (packed weights of this call).                               */
+int vsr_conv_layer_fwd(int dtype, int ks, const void* x_pm, int cin_pm, const float* lr_planar, const float* w, const float* b,
+                       int cin_real, int cout_real, void* wpack, void* y_pm, int cd, float* y_planar, int act, float slope,
+                       int pixel_shuffle, int N, int H, int W, void* stream) {
+    if (bad_dtype(dtype) || !w || !wpack || bad_dims(N, H, W) || (!x_pm && !lr_planar) || (!y_pm && !y_planar) || act < ACT_NONE || act > ACT_LEAKY)
+        return VSR_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = esize(dtype);
+    float* bias = nullptr;
+    char* wp = (char*)wpack;
+    if (b) {   // the kernels read the bias as fp32 from device memory: the caller's tensor is used as is (cout_real values, padded reads are masked by cout_real)
+        bias = const_cast<float*>(b);
+    }
+    ConvArgs a = {};
+    a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1; a.out_step = 1; a.Hd = H; a.Wd = W;
+    a.act = act; a.leaky_slope = slope; a.bias = bias; a.wpack = wpack;
+    if (lr_planar) {                                       // stems: cat([lr(3), feat(64)]) or lr alone
+        if (ks != 3 || cout_real != C || !y_pm || cd != C || pixel_shuffle) return VSR_ERR_UNSUPPORTED;
+        a.CD = C; a.cout_real = C; a.dst[0] = y_pm; a.dst_nstride = pm_image_elems(H, W, C);
+        if (x_pm) {
+            if (cin_pm != C || cin_real != C + 3) return VSR_ERR_UNSUPPORTED;
+            CK(vsr_launch_pack_weights(dtype, w, wp, 9, C, C, C, C, C + 3, 3, 1, 0, 0, st));
+            CK(vsr_launch_pack_weights(dtype, w, wp + (size_t)9 * C * C * es, 9, C, 16, C, 3, C + 3, 0, 1, 0, 0, st));
+            a.src[0] = x_pm; a.src_nstride[0] = pm_image_elems(H, W, C);
+            a.src[1] = lr_planar; a.src_nstride[1] = (long long)3 * H * W;
+            return vsr_launch_conv(dtype, 3, 2, 64, 16, 1, 64, EPI_NHWC, a, st);
+        }
+        if (cin_real != 3) return VSR_ERR_UNSUPPORTED;
+        CK(vsr_launch_pack_weights(dtype, w, wp, 9, C, 16, C, 3, 3, 0, 1, 0, 0, st));
+        a.src[0] = lr_planar; a.src_nstride[0] = (long long)3 * H * W;
+        return vsr_launch_conv(dtype, 3, 1, 16, 16, 1, 64, EPI_NHWC, a, st);
+    }
+    a.src[0] = x_pm; a.src_nstride[0] = pm_image_elems(H, W, cin_pm);
+    if (ks == 3 || ks == 1) {
+        if (cin_pm != C || cin_real != C) return VSR_ERR_UNSUPPORTED;
+        if (pixel_shuffle) {
+            if (ks != 3 || cout_real != 4 * C || !y_pm || cd != C) return VSR_ERR_UNSUPPORTED;
+            for (int z = 0; z < 4; ++z) CK(vsr_launch_pack_weights(dtype, w, wp + (size_t)z * 9 * C * C * es, 9, C, C, C, C, C, 0, 4, z, 0, st));
+            // PixelShuffle(2): out[c, 2y+i, 2x+j] = conv[4c + 2i + j]: sub-conv z uses rows 4c+z and bias entries 4c+z
+            float* b4 = reinterpret_cast<float*>(wp + (size_t)4 * 9 * C * C * es);
+            if (b) for (int z = 0; z < 4; ++z) CK(vsr_launch_pack_weights(VSR_F32, b, b4 + z * C, 1, C, 1, C, 1, 1, 0, 4, z, 0, st));
+            a.bias = b ? b4 : nullptr; a.bias_zstride = C; a.nz = 4; a.w_zstride = 9 * C * C;
+            a.out_step = 2; a.Hd = 2 * H; a.Wd = 2 * W; a.CD = C; a.cout_real = C; a.dst_nstride = pm_image_elems(2 * H, 2 * W, C);
+            for (int z = 0; z < 4; ++z) { a.dst[z] = y_pm; a.out_oy[z] = z >> 1; a.out_ox[z] = z & 1; }
+            return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+        }
+        if (cout_real != C || !y_pm || cd != C) return VSR_ERR_UNSUPPORTED;
+        CK(vsr_launch_pack_weights(dtype, w, wp, ks * ks, C, C, C, C, C, 0, 1, 0, 0, st));
+        a.CD = C; a.cout_real = C; a.dst[0] = y_pm; a.dst_nstride = pm_image_elems(H, W, C);
+        return vsr_launch_conv(dtype, ks, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+    }
+    if (ks != 7 || pixel_shuffle) return VSR_ERR_UNSUPPORTED;
+    for (int j = 0; j < NSPY; ++j) {
+        if (cin_pm != SPY_CIP[j] || cout_real != SPY_CO[j] || cin_real != SPY_CI[j]) continue;
+        CK(vsr_launch_pack_weights(dtype, w, wp, 49, SPY_COP[j], SPY_CIP[j], SPY_CO[j], SPY_CI[j], SPY_CI[j], 0, 1, 0, 0, st));
+        a.cout_real = SPY_CO[j];
+        if (j < NSPY - 1) {
+            if (!y_pm || cd != SPY_CD[j]) return VSR_ERR_BADARG;
+            a.dst[0] = y_pm; a.CD = SPY_CD[j]; a.dst_nstride = pm_image_elems(H, W, SPY_CD[j]);
+            return vsr_launch_conv(dtype, 7, 1, SPY_CIP[j], SPY_CIP[j], 0, SPY_COP[j], EPI_NHWC, a, st);
+        }
+        if (!y_planar) return VSR_ERR_BADARG;
+        a.dst[0] = y_planar; a.dst_nstride = (long long)2 * H * W;
+        return vsr_launch_conv(dtype, 7, 1, 16, 16, 0, 32, EPI_PLANAR, a, st);
+    }
+    return VSR_ERR_UNSUPPORTED;
+}
+
 size_t vsr_conv3x3_c64_wgrad_slab_floats(void) {
     int cp, xp, stride;
     vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);

@@ -774,3 +774,96 @@ def window_attention_core(qkv_self: torch.Tensor, qkv_mut: Optional[torch.Tensor
     if (C3 // 3 // heads) > 32 or N % 32 != 0 or N > 384 or (qkv_mut is not None and N % 64 != 0):
         raise NotImplementedError("HIP window attention: head_dim <= 32 and windows of 64..384 tokens (VRT's (2,8,8) / (6,8,8))")
     return _WindowAttentionFn.apply(qkv_self, qkv_mut, table, index[:N, :N], mask, heads, scale, resolve_dtype(compute_dtype))
+
+
+# --------------------------------------------------------------------------------------------- #
+# single conv layers of the reference's building blocks, forward only (inference / composition of custom pipelines)
+# --------------------------------------------------------------------------------------------- #
+def _no_grad_only(what: str, *tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(f"{what} is inference-only on the HIP path when called on its own (its backward runs inside the "
+                                  "BasicVSR / SPyNet engines): call it under torch.no_grad()")
+
+
+def conv_layer(x_pm: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0, slope: float = 0.1,
+               lr_planar: Optional[torch.Tensor] = None, pixel_shuffle: bool = False, planar_out: bool = False,
+               dtype: Optional[int] = None, hw: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """``vsr_conv_layer_fwd``: one conv layer on a blocked pixel-major tensor (or the planar LR frames).  Returns a
+    pixel-major tensor, or (N,cout,H,W) fp32 when ``planar_out``."""
+    lib = _lib.load()
+    cout, cin, ks, _ = weight.shape
+    if x_pm is not None:
+        n, h, w, cin_pm = _pm_dims(x_pm)
+        dt = DT_BF16 if x_pm.dtype == torch.bfloat16 else DT_F32
+        dev = x_pm.device
+    else:
+        n, h, w = hw
+        cin_pm, dt, dev = 0, dtype, lr_planar.device
+    wpack = torch.empty(49 * 64 * 64 * 4, dtype=_TORCH_DT[dt], device=dev)
+    y_pm = y_pl = None
+    cd = 0
+    if planar_out:
+        y_pl = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev)
+    else:
+        cd = 64 if pixel_shuffle else max(16, cout)
+        s = 2 if pixel_shuffle else 1
+        y_pm = torch.empty((n, s * h, (s * w + 31) // 32, cd // 8, 32, 8), dtype=_TORCH_DT[dt], device=dev)
+        y_pm.pm_w = s * w
+    _lib.check(lib.vsr_conv_layer_fwd(dt, ks, _ptr(x_pm), cin_pm, _ptr(None if lr_planar is None else _f32c(lr_planar)), _ptr(_f32c(weight)),
+                                      _ptr(None if bias is None else _f32c(bias)), cin, cout, _ptr(wpack), _ptr(y_pm), cd, _ptr(y_pl),
+                                      act, float(slope), int(pixel_shuffle), n, h, w, _stream()), "conv_layer_fwd")
+    return y_pl if planar_out else y_pm
+
+
+def conv_relu_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """ConvReLU.forward (core/modules/conv.py:15-22) for the SPyNet layer shapes (7x7) and 64 -> 64 (3x3 / 1x1)."""
+    _require_gpu(x)
+    _no_grad_only("ConvReLU", x, weight, bias)
+    dt = resolve_dtype(compute_dtype)
+    cout, cin = weight.shape[:2]
+    xp = to_pixel_major(x, dt, ((cin + 15) // 16) * 16)
+    if cout <= 4:
+        return conv_layer(xp, weight, bias, act=1, planar_out=True)
+    return from_pixel_major(conv_layer(xp, weight, bias, act=1), cout)
+
+
+def spynet_module_forward(x: torch.Tensor, params: Sequence[torch.Tensor], last_relu: bool = True,
+                          compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """SpynetModule.forward (spynet.py:13-21): (N,8,h,w) -> (N,2,h,w) through the five 7x7 layers."""
+    _require_gpu(x)
+    _no_grad_only("SpynetModule", x, *params)
+    if x.shape[1] != 8 or len(params) != 10:
+        raise ValueError("SpynetModule takes (N,8,h,w) and has 10 parameter tensors")
+    y = to_pixel_major(x, resolve_dtype(compute_dtype), 16)
+    for j in range(4):
+        y = conv_layer(y, params[2 * j], params[2 * j + 1], act=1)
+    return conv_layer(y, params[8], params[9], act=1 if last_relu else 0, planar_out=True)
+
+
+def pixel_shuffle_pack_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], compute_dtype: Optional[str] = None):
+    """PixelShufflePack.forward (upsampling.py:10-12): conv3x3 64 -> 256 + PixelShuffle(2); the shuffle is the store pattern."""
+    _require_gpu(x)
+    _no_grad_only("PixelShufflePack", x, weight, bias)
+    if x.shape[1] != 64 or tuple(weight.shape) != (256, 64, 3, 3):
+        raise NotImplementedError("the HIP PixelShufflePack is built for 64 -> 64 channels, scale 2 (the reference's use)")
+    return from_pixel_major(conv_layer(to_pixel_major(x, resolve_dtype(compute_dtype)), weight, bias, pixel_shuffle=True), 64)
+
+
+def residual_block_forward(x: torch.Tensor, stem_w: torch.Tensor, stem_b: torch.Tensor, blocks: Sequence[Tuple[torch.Tensor, ...]],
+                           compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """ResidualBlock.forward (core/modules/conv.py:94-103) on x = cat([lr(3), feat(64)]) (the trunks) or x = lr (the pre-clean
+    stack): conv3x3 + LeakyReLU(0.1), then the ResidualConv blocks ((w1, b1, w2, b2) each)."""
+    _require_gpu(x)
+    _no_grad_only("ResidualBlock", x, stem_w, stem_b)
+    n, cin, h, w = x.shape
+    dt = resolve_dtype(compute_dtype)
+    if cin == 67:
+        y = conv_layer(to_pixel_major(x[:, 3:].contiguous(), dt), stem_w, stem_b, act=2, lr_planar=x[:, :3].contiguous())
+    elif cin == 3:
+        y = conv_layer(None, stem_w, stem_b, act=2, lr_planar=x, dtype=dt, hw=(n, h, w))
+    else:
+        raise NotImplementedError("the HIP ResidualBlock stem takes 3 (pre-clean) or 3 + 64 (trunk) input channels")
+    for (w1, b1, w2, b2) in blocks:
+        a = conv3x3_c64(y, w1, b1, act=1)
+        y = conv3x3_c64(a, w2, b2, act=0, res_pm=y)
+    return from_pixel_major(y)

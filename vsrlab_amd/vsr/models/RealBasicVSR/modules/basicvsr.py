@@ -49,13 +49,12 @@ class BasicVSR(nn.Module):
         return [sd[k] for k in keys], n_trainable
 
     def compute_flow(self, lrs):
-        """(flow_forward, flow_backward), each (n*(t-1),2,h,w)  (reference basicvsr.py:30-37)."""
+        """(flow_forward, flow_backward), each (n*(t-1),2,h,w): the reference's helper (basicvsr.py:30-37).  ``forward`` does
+        not call it (the engine computes the flows itself, readable with ``functional.basicvsr_flows``); here the frame
+        pairs go through the HIP SPyNet in one batched call per direction."""
         n, t, c, h, w = lrs.size()
-        lrs_1 = lrs[:, :-1, :, :, :].reshape(-1, c, h, w)
-        lrs_2 = lrs[:, 1:, :, :, :].reshape(-1, c, h, w)
-        flow_backward = self.spynet(lrs_1, lrs_2)
-        flow_forward = self.spynet(lrs_2, lrs_1)
-        return flow_forward, flow_backward
+        earlier, later = lrs[:, :-1].reshape(-1, c, h, w), lrs[:, 1:].reshape(-1, c, h, w)
+        return self.spynet(later, earlier), self.spynet(earlier, later)
 
     def forward(self, lrs):
         tensors, n_trainable = self._ordered_tensors()

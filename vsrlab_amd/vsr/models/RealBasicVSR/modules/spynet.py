@@ -23,7 +23,10 @@ class SpynetModule(nn.Module):
                                           ConvReLU(32, 16, 7, 1, 3), ConvReLU(16, 2, 7, 1, 3))
 
     def forward(self, x):
-        raise NotImplementedError("SpynetModule is fused into the SPyNet engine; call Spynet(ref, supp)")
+        params = []
+        for m in self.basic_module:
+            params += [m.conv[0].weight, m.conv[0].bias]
+        return VF.spynet_module_forward(x, params, last_relu=True)
 
 
 class Spynet(nn.Module):
