@@ -317,14 +317,14 @@ int launch_wgrad_inst(const WgradArgs& a0, int nwg, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------
 // bf16, 3x3, 64 -> 64: the shape that carries ~all weight-gradient FLOPs.  Same maths as wgrad_kernel,
-// restructured around the memory system (this GEMM streams X and dY exactly once: at MFMA speed it would
-// need > 8 TB/s, so it is HBM-bound and everything is about keeping loads in flight):
-//   * ONE 512-thread workgroup per CU; both operand tiles are DOUBLE-BUFFERED in LDS (2 x 74.5 KiB) and
-//     filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), issued one whole tile
-//     ahead of the MFMAs.  The swizzle for the transposing reads is applied on the per-lane SOURCE address;
-//     out-of-image pixels read a 16-byte zero word, so border tiles need no special path.
-//   * 8 waves = (cout-block, cin-block, row-half): each wave keeps 9 taps x 32x32 in 144 accumulator
-//     registers and covers 4 of the tile's 8 rows; the two row-halves write separate slabs.
+// restructured around the memory system (this GEMM streams X and dY exactly once: it is HBM-bound and
+// everything is about keeping loads in flight):
+//   * ONE 512-thread workgroup per CU; both operand tiles are DOUBLE-BUFFERED in LDS (2 x 80 KiB = all of
+//     a CU's LDS) and filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), issued
+//     one whole tile ahead of the MFMAs.  The swizzle-free padded images below make the transposing reads
+//     bank-conflict-free; out-of-image pixels read a 16-byte zero word, so border tiles need no special path.
+// (Round 1's kernel of this shape -- all 8 waves doing DMA then MFMA, 41 us per frame-conv -- was replaced by
+//  the producer / consumer kernel below, 29 us: profiles/r02_bench_kernel_stats_single_stream.csv.)
 // ---------------------------------------------------------------------------------------------------
 __device__ uint4 g_zero_chunk[2];
 
@@ -343,235 +343,6 @@ constexpr int DX_PIECES = DX_SLOTS / 64;             // 45
 constexpr int DY_PIECES = DY_SLOTS / 64;             // 35
 constexpr int DNT = 512;
 static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
-
-// Diagnostic build only (make STAMPS=1): per-wave cycle sums of the phases of a tile, to a buffer of their own.
-#ifdef VSR_STAMPS
-__device__ unsigned long long g_wg_stamps[256 * 8 * 8];
-__device__ __forceinline__ unsigned long long wstamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define WSTAMP(var) const unsigned long long var = wstamp()
-#define WSTAMP_ADD(slot, a, b) wst[slot] += (b) - (a)
-#else
-#define WSTAMP(var)
-#define WSTAMP_ADD(slot, a, b)
-#endif
-
-__global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_dma_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int cb = wave & 1, ib = (wave >> 1) & 1, kh = wave >> 2;
-
-    f32x16_t acc[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    float bsum[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-
-    const int tiles_per_img = a.ntiles_x * a.ntiles_y;
-    const int per_seg = a.N * tiles_per_img;
-    const int total = a.nseg * per_seg;
-    const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
-
-    // DMA pieces of this wave: piece = wave + 8 i (45 X pieces, then 35 dY pieces), 64 consecutive LDS slots each.
-    // slot -> (row, chunk, pixel tx); rel[i] = source byte offset from the tile's origin in the blocked layout
-    // (valid for interior tiles; pad slots read the zero word).  pad[i]: this lane's slot is padding.
-    constexpr int NPIECE = (DX_PIECES + DY_PIECES) / 8;           // 10
-    static_assert((DX_PIECES + DY_PIECES) % 8 == 0, "even split over 8 waves");
-    int rel[NPIECE];
-    unsigned padmask = 0;
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-        const int piece = wave + 8 * i;
-        if (piece < DX_PIECES) {
-            const int idx = piece * 64 + lane;
-            const int row = idx / (8 * XS), rem = idx - row * (8 * XS);
-            const int c = rem / XS, tx = rem - c * XS;
-            const int dx = (tx - 1) * a.x_step + a.x_ox;
-            rel[i] = (((((row - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
-            if (tx >= TW + 2) padmask |= 1u << i;
-        } else {
-            const int idx = (piece - DX_PIECES) * 64 + lane;
-            const int row = idx / (8 * YS), rem = idx - row * (8 * YS);
-            const int c = rem / YS, tx = rem - c * YS;
-            const int dx = tx * a.dy_step + a.dy_ox;
-            rel[i] = ((((row * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
-            if (tx >= TW) padmask |= 1u << i;
-        }
-    }
-    auto issue = [&](int T, int s) {
-        const int seg = T / per_seg;
-        const int r0 = T - seg * per_seg;
-        const int n = r0 / tiles_per_img;
-        const int r1 = r0 - n * tiles_per_img;
-        const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
-        const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
-        const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
-        const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, 0, a.Wx, 64) * 2;      // tx0*step: multiple of 32
-        const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, 0, a.Wy, 64) * 2;
-        char* lxs = smem + s * DSET;
-        const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;              // wave-uniform
-#pragma unroll
-        for (int i = 0; i < NPIECE; ++i) {
-            const int piece = wave + 8 * i;
-            const bool isx = piece < DX_PIECES;
-            const char* src = (isx ? xo : yo) + rel[i];
-            bool valid = !((padmask >> i) & 1u);
-            if (!interior && valid) {
-                if (isx) {
-                    const int idx = piece * 64 + lane;
-                    const int row = idx / (8 * XS), tx = (idx - row * (8 * XS)) % XS;
-                    const int vy = ty0 + row - 1, vx = tx0 + tx - 1;
-                    valid = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
-                } else {
-                    const int idx = (piece - DX_PIECES) * 64 + lane;
-                    const int row = idx / (8 * YS), tx = (idx - row * (8 * YS)) % YS;
-                    valid = ty0 + row < a.H && tx0 + tx < a.W;
-                }
-            }
-            if (!valid) src = zsrc;
-            char* dst = isx ? lxs + piece * 1024 : lxs + DXB + (piece - DX_PIECES) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-
-#ifdef VSR_STAMPS
-    unsigned long long wst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long wbegin = wstamp();
-#endif
-    int cur = 0;
-    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
-    int T = walk.first;
-    if (T < walk.end) issue(T, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // transposing-read addresses: lane 4q+p of a 16-lane group supplies row (= pixel) q, columns (= channels) 4p..4p+3
-    const int g2 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
-    const int chy = cb * 32 + 16 * g2 + p4, chx = ib * 32 + 16 * g2 + p4;
-    const int ybase = (chy >> 3) * (YS * 16) + (8 * h + q4) * 16 + (chy & 7) * 2;
-    const int xbase = (chx >> 3) * (XS * 16) + (8 * h + q4) * 16 + (chx & 7) * 2;
-    for (; T < walk.end; T += walk.stride) {
-        const int next = T + walk.stride;
-        WSTAMP(w0);
-        // Requested a tile ahead, but NOT overlapped with this tile's K loop: hipcc assumes the LDS-DMA may alias
-        // the LDS reads below and waits for it (s_waitcnt vmcnt(0)) in front of the first of them, and the variants
-        // that do overlap (inline-asm DMA in one burst; pieces spread through the K loop; staggered bursts)
-        // all measured SLOWER, 85-134 us against 76 us per frame: an LDS-DMA piece issued beside the K loop's
-        // ds_read stream sits ~1.2 k cycles in the memory pipe instead of ~0.5 k (in-kernel stamps).
-        if (next < walk.end) issue(next, cur ^ 1);
-        WSTAMP(w1);
-        const char* lx = smem + cur * DSET;
-        const char* ly = lx + DXB;
-        // bias partial sums: this thread's channel chunk (tid & 7) of 4 pixels of the dY tile
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = (tid >> 3) + 64 * i;
-            chunk_sum(*reinterpret_cast<const uint4*>(ly + (p >> 5) * YROW + (tid & 7) * (YS * 16) + (p & 31) * 16), bsum);
-        }
-        WSTAMP(w2);
-        // K loop.  All LDS addresses are lane-constant base + wave-uniform row offset + immediate
-        // (per-read address arithmetic made an earlier version VALU-bound: ~150 VALU per 9 MFMAs).
-#pragma unroll 1
-        for (int r2 = 0; r2 < 2; ++r2) {         // 144 accumulators: keep the body small
-            // 12 groups g = (k-step ks = rr*2 + half, ky): 3 MFMAs each.  The B fragments of group g+2 and the
-            // A fragment of the next k-step are requested before group g's MFMAs issue, so an LDS round trip
-            // (~130 cycles) is covered by 6 MFMAs instead of being waited for in front of every MFMA.
-            typedef union { s16x4_t s[2]; bf16x8_t b; } frag_u;
-            frag_u A[2], B[3][3];
-            const char* lyr = ly + ybase + (kh * 4 + r2 * 2) * YROW;
-            const char* lxr = lx + xbase + (kh * 4 + r2 * 2) * XROW;
-            auto loadA = [&](int ks, frag_u& f) {
-                const char* pa = lyr + (ks >> 1) * YROW + (ks & 1) * 256;
-                f.s[0] = tr_read(pa);
-                f.s[1] = tr_read(pa + 64);
-            };
-            auto loadB = [&](int g, frag_u* f) {
-                const int ks = g / 3, ky = g - 3 * ks, rr = ks >> 1, half = ks & 1;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const char* pb = lxr + (rr + ky) * XROW + (half * 16 + kx) * 16;
-                    f[kx].s[0] = tr_read(pb);
-                    f[kx].s[1] = tr_read(pb + 64);
-                }
-            };
-            loadA(0, A[0]);
-            loadB(0, B[0]);
-            loadB(1, B[1]);
-            // Written as a macro so that every group index is a literal: sched_group_barrier takes constants.
-            // The barrier pair pins the interleave "this group's LDS requests, then its 3 MFMAs" (hipcc
-            // otherwise sinks the reads back in front of their consumers).
-#define WG_GROUP(g)                                                                                                        \
-            {                                                                                                              \
-                constexpr int ks = (g) / 3, ky = (g) - 3 * ks;                                                             \
-                if (ky == 0 && ks + 1 < 4) loadA(ks + 1, A[(ks + 1) & 1]);                                                 \
-                if ((g) + 2 < 12) loadB((g) + 2, B[((g) + 2) % 3]);                                                        \
-                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                           \
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1].b, B[(g) % 3][kx].b, acc[ky * 3 + kx], 0, 0, 0); \
-                __builtin_amdgcn_sched_group_barrier(0x100, ((g) + 2 < 12 ? 6 : 0) + ((ky == 0 && ks + 1 < 4) ? 2 : 0), 0); \
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                         \
-            }
-            WG_GROUP(0) WG_GROUP(1) WG_GROUP(2) WG_GROUP(3) WG_GROUP(4) WG_GROUP(5)
-            WG_GROUP(6) WG_GROUP(7) WG_GROUP(8) WG_GROUP(9) WG_GROUP(10) WG_GROUP(11)
-#undef WG_GROUP
-        }
-        WSTAMP(w3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile has landed (this wave's pieces)
-        WSTAMP(w4);
-        __syncthreads();                                       // ... everybody's; and `cur` is free again
-        WSTAMP(w5);
-        WSTAMP_ADD(1, w0, w1); WSTAMP_ADD(2, w1, w2); WSTAMP_ADD(3, w2, w3); WSTAMP_ADD(4, w3, w4); WSTAMP_ADD(5, w4, w5);
-        cur ^= 1;
-    }
-#ifdef VSR_STAMPS
-    wst[0] = wstamp() - wbegin;
-    if (lane == 0 && blockIdx.x < 256)
-        for (int k = 0; k < 8; ++k) g_wg_stamps[(blockIdx.x * 8 + wave) * 8 + k] = wst[k];
-#endif
-
-    // ---- ONE partial slab per workgroup: [tap][64][64] then [64] bias sums.  The two row-halves (waves kh = 0 / 1 of
-    // the same (cb, ib)) are summed through LDS first: half the slab traffic here and in the reduction. ----
-    __syncthreads();                                           // the tile buffers are free
-    float* xch = reinterpret_cast<float*>(smem);               // [4 pairs][144][64 lanes] fp32 = 147,456 B
-    const int pair = wave & 3;
-    if (kh == 1) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[((pair * 144) + tap * 16 + r) * 64 + lane] = acc[tap][r];
-    }
-    __syncthreads();
-    if (kh == 0) {
-        float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                slab[((long long)tap * 64 + co) * 64 + ib * 32 + l31] = acc[tap][r] + xch[((pair * 144) + tap * 16 + r) * 64 + lane];
-            }
-    }
-    __syncthreads();                                           // xch consumed before `red` reuses the space
-    float* red = reinterpret_cast<float*>(smem);               // [512][8]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
-    __syncthreads();
-    if (tid < 64) {
-        float s = 0.f;
-        const int c = tid >> 3, j = tid & 7;                   // thread t summed chunk (t & 7)
-        for (int t = c; t < DNT; t += 8) s += red[t * 8 + j];
-        a.slab[(long long)blockIdx.x * a.slab_stride + 9 * 64 * 64 + tid] = s;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Producer / consumer form of the same kernel (round 2).  The DMA kernel above serialises a tile's memory
@@ -796,25 +567,8 @@ int launch_wgrad_pc(const WgradArgs& a0, int nwg, hipStream_t st) {      // nwg 
     return VSR_OK;
 }
 
-int launch_wgrad_dma(const WgradArgs& a0, int nwg, hipStream_t st) {     // nwg workgroups = nwg slabs
-    constexpr int LDS = 2 * DSET;                              // 163,840: all of a CU's LDS
-    static VsrDevOnce once;
-    { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(wgrad3x3_c64_dma_kernel), LDS); if (rc != VSR_OK) return rc; }
-    WgradArgs a = a0;
-    a.ntiles_x = cdiv(a.W, TW);
-    a.ntiles_y = cdiv(a.H, TH);
-    hipLaunchKernelGGL(wgrad3x3_c64_dma_kernel, dim3(nwg), dim3(DNT), LDS, st, a);
-    HIP_CHECK_RET(hipGetLastError());
-    return VSR_OK;
-}
-
 }  // namespace
 
-#ifdef VSR_STAMPS
-extern "C" int vsr_debug_read_wgrad_stamps(unsigned long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : -3;
-}
-#endif
 
 #define VSR_WGRAD_SHAPES(X)           \
     X(3, 64, false, 64, false)        /* trunk / upsample / conv_last.0 */ \
@@ -843,12 +597,9 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
     {   // hot shape: LDS-DMA double-buffered kernel (needs an even slab count: 2 row-halves per workgroup)
         static int force_generic = -1;
         if (force_generic < 0) { const char* e = getenv("VSRLAB_AMD_GENERIC_WGRAD"); force_generic = (e && e[0] == '1') ? 1 : 0; }
-        static int v1 = -1;
-        if (v1 < 0) { const char* e = getenv("VSRLAB_AMD_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
         if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2) {
             *nslabs = nwg / 2;                                 // one 512-thread workgroup per CU, one slab each
-            const bool sliced = a.x_ctotal || a.x_coff || a.dy_ctotal || a.dy_coff;
-            return (v1 && !sliced) ? launch_wgrad_dma(a, nwg / 2, st) : launch_wgrad_pc(a, nwg / 2, st);
+            return launch_wgrad_pc(a, nwg / 2, st);
         }
     }
 #define X(KS, CX, XP, COUT, DP)                                                                        \

@@ -497,6 +497,8 @@ class _CleanerFn(torch.autograd.Function):
         mid_channels, blocks, steps, dtype, need_bwd = ctx.meta
         if not need_bwd:
             raise RuntimeError("vsrlab_amd: backward through a pre-clean forward that ran without need_backward")
+        if ctx.ws is None:
+            raise RuntimeError("vsrlab_amd: trying to backward through the pre-clean graph a second time")
         n, t, _, h, w = dlq.shape
         lib = _lib.load()
         grads = [torch.zeros(sh, dtype=torch.float32, device=dlq.device) for sh in ctx.shapes]
