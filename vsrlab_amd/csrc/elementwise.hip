@@ -120,6 +120,165 @@ __global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gather form of the same backward for the propagation warps inside the engine (round 2).  The scatter above pushes
+// 4 taps x 64 channels x 4 B of fp32 atomics per pixel through the memory-side atomic units (1.3 TB/s: 450 us per 540p
+// frame) into an accumulator that then needs a memset and a read-back.  Optical flows are smooth and a few pixels long, so
+// the adjoint is computed from the DESTINATION side instead:
+//     dIn[yi][xi] = sum over sources (y, x) whose sample position (x + fx, y + fy) lies within one pixel of (xi, yi)
+//                   of  w(y, x -> yi, xi) * dOut[y][x]
+//   * a workgroup owns an 8 x 32 tile of dIn; the sample positions of the sources in the tile + R halo go to LDS once;
+//   * phase 1: one thread per destination pixel scans the (2R+1)^2 candidate sources and records its hits (source, weight)
+//     in a short LDS list (bilinear footprint: ~4 hits per pixel);
+//   * phase 2: 8 lanes per destination pixel (one 16-byte channel chunk each) walk the list, accumulate in fp32 registers
+//     in a FIXED order and write T(dtop + sum) -- the add_cast of the scatter form is fused, nothing is atomic, the result is
+//     bitwise reproducible;
+//   * sources displaced by more than R - 1 pixels ("far") are skipped here and scattered with atomics by
+//     warp_bwd_far_kernel into the fp32 accumulator S, which this kernel adds (and re-zeroes) only when the launch's
+//     far counter is non-zero: correct for any flow, fast for the flows SPyNet produces.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GR = 5;                                   // search radius: sources within +-5 pixels; |flow| <= 4 is "near"
+constexpr int GTH = 8, GTW = 32, GCAP = 8;
+constexpr int GHH = GTH + 2 * GR, GHW = GTW + 2 * GR;   // 18 x 42 sources per tile
+
+__device__ __forceinline__ bool flow_is_far(float fx, float fy) {
+    return !(fabsf(fx) <= (float)(GR - 1) && fabsf(fy) <= (float)(GR - 1));      // NaN counts as far
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const T* __restrict__ dout, const float* __restrict__ flow, const T* __restrict__ dtop,
+                                                              float* __restrict__ S, const int* __restrict__ far_count, T* __restrict__ out,
+                                                              int N, int H, int W, long long flow_nstride) {
+    constexpr int C = 64;
+    typedef typename EW<T>::chunk_t chunk_t;
+    __shared__ float2 pos[GHH * GHW];                   // sample position of each source of the haloed tile; x = NaN: far / outside
+    __shared__ unsigned short hit_src[256 * GCAP];
+    __shared__ float hit_w[256 * GCAP];
+    __shared__ int hit_n[256];
+    const int tid = threadIdx.x;
+    const int ntx = cdiv(W, GTW), nty = cdiv(H, GTH);
+    const int tile = blockIdx.x;
+    const int n = tile / (ntx * nty), tr = tile - n * ntx * nty;
+    const int ty0 = (tr / ntx) * GTH, tx0 = (tr % ntx) * GTW;
+    const float* fbase = flow + (long long)n * flow_nstride;
+    const long long img = (long long)n * pm_image_elems(H, W, C);
+    for (int i = tid; i < GHH * GHW; i += 256) {
+        const int sy = ty0 - GR + i / GHW, sx = tx0 - GR + i % GHW;
+        float2 p = make_float2(__int_as_float(0x7fc00000), 0.f);
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            const float fx = fbase[(long long)sy * W + sx], fy = fbase[(long long)H * W + (long long)sy * W + sx];
+            if (!flow_is_far(fx, fy)) p = make_float2(warp_coord((float)sx, fx, W), warp_coord((float)sy, fy, H));
+        }
+        pos[i] = p;
+    }
+    __syncthreads();
+    {   // phase 1: hits of destination pixel tid
+        const int dy = tid >> 5, dx = tid & 31;
+        const int yi = ty0 + dy, xi = tx0 + dx;
+        int cnt = 0;
+        if (yi < H && xi < W) {
+            for (int sy = 0; sy <= 2 * GR; ++sy)
+                for (int sx = 0; sx <= 2 * GR; ++sx) {
+                    const int si = (dy + sy) * GHW + dx + sx;
+                    const float2 p = pos[si];
+                    const float fx0 = floorf(p.x), fy0 = floorf(p.y);
+                    const int ox = xi - (int)fx0, oy = yi - (int)fy0;          // 0 or 1 for a hit (NaN -> no hit)
+                    if (p.x == p.x && (unsigned)ox <= 1u && (unsigned)oy <= 1u) {
+                        const float wx1 = p.x - fx0, wy1 = p.y - fy0;
+                        const float wgt = (ox ? wx1 : 1.f - wx1) * (oy ? wy1 : 1.f - wy1);
+                        if (cnt < GCAP) { hit_src[tid * GCAP + cnt] = (unsigned short)si; hit_w[tid * GCAP + cnt] = wgt; }
+                        ++cnt;
+                    }
+                }
+        }
+        hit_n[tid] = cnt;
+    }
+    __syncthreads();
+    const bool add_far = far_count[0] != 0;
+    const int c = tid & 7;
+    for (int pass = 0; pass < 8; ++pass) {              // phase 2: 32 destination pixels per pass, 8 lanes (chunks) each
+        const int d = pass * 32 + (tid >> 3);
+        const int dy = d >> 5, dx = d & 31;
+        const int yi = ty0 + dy, xi = tx0 + dx;
+        if (yi >= H || xi >= W) continue;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int cnt = hit_n[d];
+        if (cnt <= GCAP) {
+            for (int k = 0; k < cnt; ++k) {
+                const int si = hit_src[d * GCAP + k];
+                const float wgt = hit_w[d * GCAP + k];
+                const int sy = ty0 - GR + si / GHW, sx = tx0 - GR + si % GHW;
+                float f[8];
+                unpack8(*reinterpret_cast<const chunk_t*>(dout + img + pm_off(sy, sx, c, W, C)), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
+            }
+        } else {                                        // more sources converge on this pixel than the list holds: rescan (rare)
+            for (int sy = 0; sy <= 2 * GR; ++sy)
+                for (int sx = 0; sx <= 2 * GR; ++sx) {
+                    const int si = (dy + sy) * GHW + dx + sx;
+                    const float2 p = pos[si];
+                    const float fx0 = floorf(p.x), fy0 = floorf(p.y);
+                    const int ox = xi - (int)fx0, oy = yi - (int)fy0;
+                    if (p.x == p.x && (unsigned)ox <= 1u && (unsigned)oy <= 1u) {
+                        const float wx1 = p.x - fx0, wy1 = p.y - fy0;
+                        const float wgt = (ox ? wx1 : 1.f - wx1) * (oy ? wy1 : 1.f - wy1);
+                        float f[8];
+                        unpack8(*reinterpret_cast<const chunk_t*>(dout + img + pm_off(ty0 - GR + dy + sy, tx0 - GR + dx + sx, c, W, C)), f);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
+                    }
+                }
+        }
+        if (add_far) {                                  // the atomically scattered share; S goes back to all-zero
+            float4* sp = reinterpret_cast<float4*>(S + (((long long)n * H + yi) * W + xi) * C + c * 8);
+            const float4 s0 = sp[0], s1 = sp[1];
+            acc[0] += s0.x; acc[1] += s0.y; acc[2] += s0.z; acc[3] += s0.w; acc[4] += s1.x; acc[5] += s1.y; acc[6] += s1.z; acc[7] += s1.w;
+            sp[0] = make_float4(0.f, 0.f, 0.f, 0.f); sp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const long long o = img + pm_off(yi, xi, c, W, C);
+        if (dtop) {
+            float t[8];
+            unpack8(*reinterpret_cast<const chunk_t*>(dtop + o), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += t[j];
+        }
+        chunk_t r;
+        pack8(acc, r);
+        *reinterpret_cast<chunk_t*>(out + o) = r;
+    }
+}
+
+// the "far" sources of the gather form: |flow| > GR - 1 (or non-finite): scattered with atomics like warp_bwd_kernel, and counted
+template <typename T>
+__global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __restrict__ flow, float* __restrict__ S, int* __restrict__ far_count,
+                                    int N, int H, int W, long long flow_nstride) {
+    constexpr int C = 64;
+    const long long total = (long long)N * H * W;
+    for (long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pix < total; pix += (long long)gridDim.x * (blockDim.x >> 6)) {
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+        const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
+        const float fx = fp[0], fy = fp[(long long)H * W];
+        if (!flow_is_far(fx, fy)) continue;             // wave-uniform: one wave per pixel, lane = channel
+        const int c = threadIdx.x & 63;
+        if (c == 0) atomicAdd(far_count, 1);
+        const float px = warp_coord((float)x, fx, W), py = warp_coord((float)y, fy, H);
+        if (!(px == px && py == py)) continue;
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        if (fabsf(fx0) > 1e9f || fabsf(fy0) > 1e9f) continue;
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const float g = (float)dout[(long long)n * pm_image_elems(H, W, C) + pm_off(y, x, c >> 3, W, C) + (c & 7)];
+        float* imgp = S + (long long)n * H * W * C;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+            const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+            if (xi >= 0 && xi < W && yi >= 0 && yi < H) atomicAdd(imgp + ((long long)yi * W + xi) * C + c, g * wgt);
+        }
+    }
+}
+
 // out = T(a + s)   a, out: blocked pixel-major T (a may be null); s: plain [N][H][W][C] fp32 (the warp scatter
 // accumulator) or null.  One thread per (pixel, 8-channel chunk).
 template <typename T>
@@ -627,6 +786,22 @@ int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* d
                         long long flow_nstride, hipStream_t st, int border) {
     const long long total = (long long)N * H * W * C;
     DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)dout, flow, dacc, N, H, W, C, flow_nstride, border));
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+// out = T(dtop + warp^T(dout)) for the 64-channel propagation warps (zeros padding): gather kernel + far-source scatter.
+// S: fp32 [N][H][W][64], ALL ZERO on entry and on exit; far_count: one int, zero on entry (the number of far sources on exit).
+int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, const void* dtop, float* S, int* far_count, void* out,
+                               int N, int H, int W, long long flow_nstride, hipStream_t st) {
+    if (!dout || !flow || !S || !far_count || !out) return VSR_ERR_BADARG;
+    const long long npix = (long long)N * H * W;
+    const int tiles = N * cdiv(H, GTH) * cdiv(W, GTW);
+    long long gb = (npix + 3) / 4;
+    if (gb > 256 * 16) gb = 256 * 16;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_far_kernel<T>, dim3((int)gb), dim3(256), 0, st, (const T*)dout, flow, S, far_count, N, H, W, flow_nstride));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_gather_kernel<T>, dim3(tiles), dim3(256), 0, st, (const T*)dout, flow, (const T*)dtop, S,
+                                         (const int*)far_count, (T*)out, N, H, W, flow_nstride));
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

@@ -109,6 +109,7 @@ struct Plan {
     std::vector<size_t> G0[2], G1[2], DX[2];    // G1: rb per frame, DX: (rb+1) per frame (DX[0] unused -> G0)
     std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
     size_t S[2], dWp[2], slab[2];               // per direction / stream
+    size_t far_cnt;                             // [2][t] ints: far-source counters of the gather-form warp backward
     size_t G_C0, G_U1, G_U0, G_P;
     size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow / input gradient)
     size_t stem_wd_lr[2];       // data-gradient weights of the stems' 3 LR input channels (input gradient)
@@ -178,6 +179,7 @@ struct Plan {
             dFeatB.assign(t, 0); dFF.assign(t, 0);
             for (int i = 0; i < t; ++i) { dFeatB[i] = b.take(a1); dFF[i] = b.take(a1); }
             for (int dir = 0; dir < 2; ++dir) { S[dir] = b.take(s_elems * 4); dWp[dir] = b.take(a1); }
+            far_cnt = b.take((size_t)2 * 32 * 4);
             G_C0 = b.take(a4); G_U1 = b.take(a4); G_U0 = b.take(a2); G_P = b.take(a1);
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
@@ -671,9 +673,17 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
 }
 
 // BPTT through one ResidualBlock call; top gradient = dtop (T) + S (fp32 scatter, optional)
-int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, bool add_scatter, bool has_warp) {
+// pending_flow: the flow of the warp whose output gradient sits in dWp[dir] (from the previous frame of the chain), or null:
+// the top gradient of this frame is dtop + warp^T(dWp) -- gather form, fused with the cast (elementwise.hip)
+int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, const float* pending_flow, int pending_k, bool has_warp) {
     const int n = p.n, h = p.h, w = p.w, rb = p.rb;
-    CK(vsr_launch_add_cast(c.dtype, dtop, add_scatter ? c.fat(p.S[dir]) : nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
+    if (pending_flow) {
+        const long long fstride = (long long)(p.t - 1) * 2 * h * w;
+        CK(vsr_launch_warp_bwd_gather(c.dtype, c.at(p.dWp[dir]), pending_flow, dtop, (float*)c.at(p.S[dir]),
+                                      (int*)c.at(p.far_cnt) + dir * 32 + pending_k, c.at(p.dxoff(dir, i, rb)), n, h, w, fstride, c.st));
+    } else {
+        CK(vsr_launch_add_cast(c.dtype, dtop, nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
+    }
     for (int b = rb - 1; b >= 0; --b) {
         const void* dxn = c.at(p.dxoff(dir, i, b + 1));
         // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
@@ -729,15 +739,19 @@ int trunk_wgrads(const Ctx& c, const Plan& p, int dir, const float* lrs, float* 
 int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float* const* g) {
     const int n = p.n, t = p.t, h = p.h, w = p.w;
     const long long fstride = (long long)(t - 1) * 2 * h * w;
+    // the gather-form warp backward keeps S all-zero between uses: ONE memset per chain (was one per frame)
+    HIP_CHECK_RET(hipMemsetAsync(c.at(p.S[dir]), 0, p.s_elems * 4, c.st));
+    HIP_CHECK_RET(hipMemsetAsync((int*)c.at(p.far_cnt) + dir * 32, 0, 32 * 4, c.st));
+    const float* pending = nullptr;
     for (int k = 0; k < t; ++k) {
         // the state of dir 1 flows 0 -> t-1, so its gradient flows t-1 -> 0; dir 0 the other way round
         const int i = dir == 1 ? t - 1 - k : k;
         const void* dtop = dir == 1 ? c.at(p.dFF[i]) : c.at(p.dFeatB[i]);
         const bool last = k == t - 1;                     // the chain's first frame had no warped state
-        CK(trunk_backward(c, p, dir, i, dtop, k > 0, !last));
-        if (!last) {   // feat(i) = trunk(warp(feat(prev), flow)): scatter the gradient of the warped state back
-            HIP_CHECK_RET(hipMemsetAsync(c.at(p.S[dir]), 0, p.s_elems * 4, c.st));
-            CK(vsr_launch_warp_bwd(c.dtype, c.at(p.dWp[dir]), flow_ptr(c, p, dir, dir == 1 ? i - 1 : i), (float*)c.at(p.S[dir]), n, h, w, C, fstride, c.st));
+        CK(trunk_backward(c, p, dir, i, dtop, pending, k, !last));
+        pending = nullptr;
+        if (!last) {   // feat(i) = trunk(warp(feat(prev), flow)): the gradient of the warped state goes back through the warp
+            pending = flow_ptr(c, p, dir, dir == 1 ? i - 1 : i);     // ... at the top of the next frame's trunk_backward
             if (p.flowgrad) {   // the same warp's gradient w.r.t. its flow (each flow is used by exactly one warp)
                 const int prev = dir == 1 ? i - 1 : i + 1, fi = dir == 1 ? i - 1 : i;
                 float* df = (float*)c.at(p.dflows) + ((size_t)dir * p.n * (p.t - 1) + fi) * 2 * p.h * p.w;

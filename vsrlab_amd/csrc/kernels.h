@@ -14,6 +14,8 @@ int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out,
                         long long flow_nstride, hipStream_t st, int border = 0);
 int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
                         long long flow_nstride, hipStream_t st, int border = 0);
+int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, const void* dtop, float* S, int* far_count, void* out,
+                               int N, int H, int W, long long flow_nstride, hipStream_t st);
 int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, int N, int H, int W, int C, hipStream_t st);
 int vsr_launch_planar_to_pm(int dtype, const float* in, void* out, int N, int Cin, int H, int W, int C, hipStream_t st);
 int vsr_launch_pm_to_planar(int dtype, const void* in, float* out, int N, int Cout, int H, int W, int C, hipStream_t st);
