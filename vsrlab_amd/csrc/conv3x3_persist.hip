@@ -319,7 +319,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += (float)rr[mb][nb].v[j];
                         }
-                        if (ACT == ACT_RELU) {
+                        if (ACT != ACT_NONE && !HAS_RES) {      // sign of the activation = sign of its argument (ReLU and LeakyReLU alike)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) sout[(mb * 4 + nb) >> 3] |= (v[j] > 0.f ? 1u : 0u) << ((((mb * 4 + nb) & 7) * 4) + j);
                         }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     }
                 }
             }
-            if (ACT == ACT_RELU && a.sign_out[z])
+            if (ACT != ACT_NONE && !HAS_RES && a.sign_out[z])
                 reinterpret_cast<uint2*>(a.sign_out[z])[(long long)tile * 256 + w4 * 64 + lane] = make_uint2(sout[0], sout[1]);
             STAMP(t3);
             __syncthreads();                               // the producers' next tile has landed; everybody has finished reading `cur`

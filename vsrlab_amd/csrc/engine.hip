@@ -105,6 +105,7 @@ struct Plan {
     size_t scratchA[2], scratchW[2];            // inference mode, per direction (the directions run concurrently)
     // reconstruction
     std::vector<size_t> Pt, U0, U1, C0;
+    std::vector<size_t> SBC0;                   // sign bits of C0 = LeakyReLU(conv_last.0) per frame (bf16 build, training)
     // backward
     std::vector<size_t> G0[2], G1[2], DX[2];    // G1: rb per frame, DX: (rb+1) per frame (DX[0] unused -> G0)
     std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
@@ -167,6 +168,9 @@ struct Plan {
         Pt.assign(t, 0); U0.assign(t, 0); U1.assign(t, 0); C0.assign(t, 0);
         for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
         for (int i = nrec; i < t; ++i) { Pt[i] = Pt[0]; U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; }
+        SBC0.assign(t, 0);
+        if (bwd && dtype == VSR_BF16)
+            for (int i = 0; i < t; ++i) SBC0[i] = b.take((size_t)n * cdiv(4 * h, 8) * cdiv(4 * w, 32) * 2048);
         if (bwd) {
             for (int dir = 0; dir < 2; ++dir) {
                 G0[dir].assign(t, 0); G1[dir].assign((size_t)t * rb, 0); DX[dir].assign((size_t)t * (rb + 1), 0);
@@ -421,7 +425,8 @@ int recon_forward(const Ctx& c, const Plan& p, int i, const float* lrs, float* s
     }
     CK(c.conv_ps(c.at(p.Pt[i]), p.up_w[0], c.fat(p.up_b[0]), c.at(p.U0[i]), n, h, w));
     CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), n, 2 * h, 2 * w));
-    CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, n, 4 * h, 4 * w));
+    CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, n, 4 * h, 4 * w,
+                (p.bwd && c.dtype == VSR_BF16) ? c.at(p.SBC0[i]) : nullptr));
     {
         ConvArgs a = c.base(n, 4 * h, 4 * w);   // conv_last.2 + bilinear x4 skip (basicvsr.py:21-22,82)
         a.src[0] = c.at(p.C0[i]); a.wpack = c.at(p.last2_w); a.bias = c.fat(p.last2_b); a.cout_real = 3;
@@ -624,7 +629,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
     const float* dsr_i = dsr + (size_t)i * 3 * H4 * W4;
     const long long dsr_ns = (long long)p.t * 3 * H4 * W4;
     if (c.dtype == VSR_BF16 && last2_w) {   // d(conv_last.0 pre-activation) = dgrad(conv_last.2)(dsr) * LeakyReLU'(C0): hr_tail.hip
-        CK(vsr_launch_last2_dgrad(dsr_i, dsr_ns, last2_w, c.at(p.C0[i]), c.at(p.G_C0), n, H4, W4, MASK_LEAKY, c.st));
+        CK(vsr_launch_last2_dgrad(dsr_i, dsr_ns, last2_w, c.at(p.C0[i]), c.at(p.G_C0), n, H4, W4, MASK_LEAKY, c.st, c.at(p.SBC0[i])));
     } else {
         ConvArgs a = c.base(n, H4, W4);
         a.src[0] = dsr_i; a.src_nstride[0] = dsr_ns; a.wpack = c.at(p.last2_wd); a.dst[0] = c.at(p.G_C0);

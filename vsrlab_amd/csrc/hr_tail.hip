@@ -15,12 +15,18 @@ constexpr int LT_RS = LT_W + 2, LT_PL = (LT_H + 2) * LT_RS;     // haloed planar
 // operand gathered from the fp32 dSR tile in LDS (k = 3 tap + c) and the A operand (flipped weights) built once per
 // workgroup from the fp32 OIHW tensor.  Output / mask addressing is the blocked pixel-major layout of common.h.
 // grid: persistent over 8x32-pixel tiles; block 256 = 4 waves, wave w covers tile rows 2w, 2w+1.
+// sign_bits (optional): the activation's signs as conv3x3_c64_persist_kernel left them, [tile][wave][lane] x 8 bytes (bit
+// (4 mb + nb) * 4 + j): this kernel uses the SAME tile decomposition and the same lane -> pixel permutation, so a lane reads
+// its own 64 bits (4 MB per 540p-sized tile set) instead of 16 x 8 bytes of the bf16 activation (the whole 1.06 GB C0 at HR).
 __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restrict__ dsr, long long dsr_nstride,
                                                             const float* __restrict__ w, const bf16_t* __restrict__ aux,
+                                                            const uint2* __restrict__ sign_bits, float neg,
                                                             bf16_t* __restrict__ dst, int N, int H, int W, int mask_mode) {
     __shared__ float tile[2][3 * LT_PL];
     const int tid = threadIdx.x, lane = tid & 63, w4 = tid >> 6;
-    const int i15 = lane & 15, q = lane >> 4;
+    const int l15 = lane & 15, q = lane >> 4;
+    // pixel of a 16-pixel block that lane column l15 works on: the persistent conv kernel's permutation (conv3x3_persist.hip)
+    const int i15 = (l15 >= 4 && l15 < 12) ? 2 * (l15 - 4) : (l15 < 4 ? 2 * l15 + 1 : 2 * (l15 - 8) + 1);
     const int ntx = cdiv(W, LT_W), nty = cdiv(H, LT_H);
     const int total = N * ntx * nty;
     const long long plane = (long long)H * W;
@@ -35,11 +41,11 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
         boff[j] = k < 27 ? c * LT_PL + ky * LT_RS + kx : -1;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const int ci = mb * 16 + i15;
+            const int ci = mb * 16 + l15;                    // A rows are indexed by the lane column itself
             fa[mb][j] = (bf16_t)(k < 27 ? w[((long long)c * 64 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.f);
         }
     }
-    const float neg = mask_mode == MASK_LEAKY ? 0.1f : 0.f;
+    (void)mask_mode;
 
     auto stage = [&](int t, int buf) {                       // haloed dSR tile -> LDS (zeros outside the image)
         const int n = t / (ntx * nty), r = t - n * (ntx * nty);
@@ -69,11 +75,13 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
             const int row = 2 * w4 + (nb >> 1), px = (nb & 1) * 16 + i15;
             ok[nb] = ty0 + row < H && tx0 + px < W;
             loff[nb] = (row * pm_ws(W) * 8 + (q >> 1)) * 256 + px * 8 + 4 * (q & 1);
-            if (aux && ok[nb]) {
+            if (aux && !sign_bits && ok[nb]) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) mm[mb][nb] = *reinterpret_cast<const bf4_t*>(aux + obase + loff[nb] + mb * 512);
             }
         }
+        uint2 sb = make_uint2(0u, 0u);
+        if (sign_bits) sb = sign_bits[(long long)t * 256 + w4 * 64 + lane];
         const int tn = t + gridDim.x;
         if (tn < total) stage(tn, buf ^ 1);                  // the other buffer: nobody reads it during this tile
         // B[k][n = pixel i] for this wave's 4 pixel blocks, then 16 MFMAs
@@ -100,7 +108,12 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[mb][nb][j];
-                    if (aux) v *= ((float)mm[mb][nb].v[j] > 0.f ? 1.f : neg);
+                    if (sign_bits) {
+                        const unsigned wbits = ((mb * 4 + nb) >> 3) ? sb.y : sb.x;
+                        v *= ((wbits >> ((((mb * 4 + nb) & 7) * 4) + j)) & 1u) ? 1.f : neg;
+                    } else if (aux) {
+                        v *= ((float)mm[mb][nb].v[j] > 0.f ? 1.f : neg);
+                    }
                     o.v[j] = (bf16_t)v;
                 }
                 *reinterpret_cast<bf4_t*>(dst + obase + loff[nb] + mb * 512) = o;
@@ -418,12 +431,13 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_kernel(const bf16_t* __r
 // dX (pixel-major bf16, 64 channels) = mask(aux) * dgrad of a 64 -> 3 3x3 conv, from the planar fp32 cotangent dsr
 // (N images `dsr_nstride` floats apart) and the conv's fp32 OIHW weight (3,64,3,3).
 int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float* w, const void* aux, void* dst, int N, int H, int W,
-                           int mask_mode, hipStream_t st) {
+                           int mask_mode, hipStream_t st, const void* sign_bits, float slope) {
     if (!dsr || !w || !dst || N < 1 || H < 1 || W < 1) return VSR_ERR_BADARG;
     const int tiles = N * cdiv(W, LT_W) * cdiv(H, LT_H);
     const int grid = tiles < 256 * 8 ? tiles : 256 * 8;
-    hipLaunchKernelGGL(last2_dgrad_kernel, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (bf16_t*)dst, N, H, W,
-                       mask_mode);
+    const float neg = mask_mode == MASK_LEAKY ? vsr_slope(slope) : 0.f;
+    hipLaunchKernelGGL(last2_dgrad_kernel, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg,
+                       (bf16_t*)dst, N, H, W, mask_mode);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

@@ -39,7 +39,7 @@ int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);
 int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride, float* slab, int slab_stride, int N, int H, int W,
                            int* nslabs, hipStream_t st);
 int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float* w, const void* aux, void* dst, int N, int H, int W,
-                           int mask_mode, hipStream_t st);
+                           int mask_mode, hipStream_t st, const void* sign_bits = nullptr, float slope = 0.f);
 int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
                             int I_total, int i_off, int o_mul, int o_add, int mode, hipStream_t st);
 int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps,
