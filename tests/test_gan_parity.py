@@ -185,3 +185,53 @@ def test_discriminator_larger_frame_and_eval_mode():
     assert rel_err(out_e, D.discriminator_forward(sd_after, img, False)) < 1e-3
     with pytest.raises(RuntimeError):
         d(torch.zeros(1, 3, 30, 48, device=dev))                 # height not a multiple of 8: loud, no fallback
+
+
+def test_config3_full_size_gan_iteration():
+    """BASELINE config 3 at its frame size, one GAN iteration through the reference-shaped step functions:
+    RealBasicVSR(cleaning_blocks=20, mid 64, res_blocks=20: conf/train/model/basicvsr.yaml) on a (1,7,3,540,960) clip, D on the
+    seven 2160x3840 frames, bf16.  generator_step -> backward -> FusedAdam, discriminator_step -> backward -> FusedAdam: finite
+    losses and gradients, parameters move, a timing line.  (Values are pinned at small sizes above; this is the at-size run:
+    ~230 GB of arenas.)"""
+    dev = _gpu()
+    import time
+    from vsrlab_amd.core.losses import AdversarialLoss, CharbonnierLoss
+    from vsrlab_amd.optim import FusedAdam
+    from vsrlab_amd.train_gan import discriminator_step, dummy_loss, generator_step
+    from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
+    torch.manual_seed(0)
+    g = RealBasicVSR(20, mid_channels=64, upscale=4, res_blocks=20, pretrained_flow=False, train_flow=False).to(dev)
+    g.basicvsr.compute_dtype = "bf16"
+    os_env = __import__("os").environ
+    os_env["VSRLAB_AMD_DTYPE"] = "bf16"
+    try:
+        d = _make_d(dev, "bf16")
+        opt_g = FusedAdam(g.parameters(), lr=1e-4, betas=(0.9, 0.99))
+        opt_d = FusedAdam(d.parameters(), lr=1e-4, betas=(0.9, 0.99))
+        lr = torch.rand(1, 7, 3, 540, 960, device=dev)
+        hr = torch.rand(1, 7, 3, 2160, 3840, device=dev)
+        adv, crit = AdversarialLoss(), CharbonnierLoss()
+        w_g0, w_d0 = opt_g.flat_params.clone(), opt_d.flat_params.clone()
+        times = []
+        for it in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sr, loss_g, perceptual_g, adv_g = generator_step(g, d, crit, dummy_loss, adv, lr, hr)
+            loss_g.backward()
+            opt_g.step(max_grad_norm=1.0)
+            opt_g.zero_grad()
+            loss_d = discriminator_step(d, adv, sr, hr)
+            loss_d.backward()
+            opt_d.step(max_grad_norm=1.0)
+            opt_d.zero_grad()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            assert bool(torch.isfinite(loss_g)) and bool(torch.isfinite(loss_d)), (float(loss_g), float(loss_d))
+        assert bool(torch.isfinite(opt_g.flat_params).all()) and bool(torch.isfinite(opt_d.flat_params).all())
+        assert float((opt_g.flat_params - w_g0).abs().max()) > 0 and float((opt_d.flat_params - w_d0).abs().max()) > 0
+        assert float(opt_g.last_grad_norm) > 0 and float(opt_d.last_grad_norm) > 0
+        print(f"config 3 (RealBasicVSR(20 clean, 20 res) + UNetDiscriminator, 540p x7, bf16): GAN iteration {times[-1] * 1e3:.0f} ms "
+              f"(first {times[0] * 1e3:.0f} ms), loss_g {float(loss_g):.4f}, loss_d {float(loss_d):.4f}, "
+              f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.0f} GiB")
+    finally:
+        del os_env["VSRLAB_AMD_DTYPE"]

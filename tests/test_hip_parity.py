@@ -277,12 +277,28 @@ def test_basicvsr_end_to_end_vs_golden(dtype):
         _noise_floor_check(grads, g_e, ref, max_glob_ratio=1.5, max_tensor_ratio=2.0)
         assert cos > 0.995
     assert not any(k.startswith("spynet") for k in grads)
-    # flows computed inside the engine
+    # flows computed inside the engine (vsr_basicvsr_get_flows on a caller-held workspace) and by the module's compute_flow
+    import vsrlab_amd
     from vsrlab_amd import functional as VF
-    ws = next(iter(m._pool._pool.values()))[0]
-    ff, fb = VF.basicvsr_flows(shape, 64, 3, 4, ws, VF.resolve_dtype(dtype), dev)
+    from vsrlab_amd._order import basicvsr_keys
+    lib = vsrlab_amd._lib.load()
+    keys, _ = basicvsr_keys(3)
+    sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 3, 4))
+    ps = [sd[k].to(dev).contiguous() for k in keys]
+    dt = VF.resolve_dtype(dtype)
+    desc = vsrlab_amd._lib.BasicVSRDesc(2, 3, 24, 40, 64, 3, 4, dt)
+    nbytes = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(desc), 0)
+    ws = VF.Workspace(nbytes, dev)
+    sr2 = torch.empty(2, 3, 3, 96, 160, device=dev)
+    st = VF._stream()
+    assert lib.vsr_basicvsr_forward(ctypes.byref(desc), VF._ptr_array(ps), len(ps), VF._ptr(lrs.to(dev)), VF._ptr(sr2), VF._ptr(ws.buf), nbytes, 0, st) == 0
+    ff, fb = VF.basicvsr_flows(shape, 64, 3, 4, ws, dt, dev)
+    assert rel_err(sr2, g["sr"]) < tol(dtype, 1e-3, 1e-2)               # inference schedule, same values
     assert rel_err(ff.reshape(-1, 2, 24, 40).cpu(), g["flow_forward"]) < tol(dtype, 1e-3, 5e-2)
     assert rel_err(fb.reshape(-1, 2, 24, 40).cpu(), g["flow_backward"]) < tol(dtype, 1e-3, 5e-2)
+    with torch.no_grad():
+        cf, cb = m.compute_flow(lrs.to(dev))                            # the reference helper (basicvsr.py:30-37)
+    assert rel_err(cf.cpu(), g["flow_forward"]) < tol(dtype, 1e-3, 5e-2) and rel_err(cb.cpu(), g["flow_backward"]) < tol(dtype, 1e-3, 5e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

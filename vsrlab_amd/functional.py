@@ -307,32 +307,34 @@ def _under_ddp() -> bool:
 
 
 class Workspace:
-    """One arena per in-flight forward.  A forward that needs a backward keeps its arena until
-    that backward has run (or its graph was dropped)."""
+    """One arena per forward, owned by that forward's autograd node (``ctx.ws``) until its backward has run or the graph is
+    dropped, then returned to PyTorch's caching allocator -- which hands the same block back to the next forward of the same
+    size without a hipMalloc, and to anybody else in between (round 2: the GAN iteration needs the generator's 87 GB for the
+    discriminator's activations while the generator is idle; a private pool that kept the arena made config 3 run out of
+    memory)."""
 
     def __init__(self, nbytes: int, device):
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.owner = None      # weakref to the autograd ctx that still needs the saved activations
-
-    def free(self) -> bool:
-        return self.owner is None or self.owner() is None
+        self.owner = None
 
 
 class WorkspacePool:
+    """Allocates arenas and remembers the most recent one WEAKLY (for ``basicvsr_flows``, which reads the flows out of a live
+    forward's arena).  It does not keep arenas alive."""
+
     def __init__(self):
-        self._pool = {}
+        self._last = None
 
     def acquire(self, key, nbytes: int, device) -> Workspace:
-        for ws in self._pool.setdefault(key, []):
-            if ws.free():
-                ws.owner = None
-                return ws
         ws = Workspace(nbytes, device)
-        self._pool[key].append(ws)
+        self._last = weakref.ref(ws)
         return ws
 
+    def last(self) -> Optional[Workspace]:
+        return self._last() if self._last is not None else None
+
     def clear(self):
-        self._pool.clear()
+        self._last = None
 
 
 class _CtxToken:
@@ -414,6 +416,7 @@ class _BasicVSRFn(torch.autograd.Function):
                    "basicvsr_backward")
         ctx.consumed = True
         ctx.ws.owner = None
+        ctx.ws = None                    # the arena goes back to the allocator now, not when the caller drops the loss tensor
         ctx.token = None
         grads: List[Optional[torch.Tensor]] = []
         for k in range(len(ps)):
