@@ -100,6 +100,9 @@ struct WgradArgs {
     int dy_planar_c;             // channels of a planar fp32 dY (DYPLANAR): 0 = 3
     int slab_stride;
     int ntiles_x, ntiles_y;
+    // pair batching (wide layers: one launch covers every (parity view, cout block, cin slice) pair of a layer):
+    // workgroup b -> pair = (b >> 3) / (ksplit / 8), pixel part = (b & 7) + 8 * ((b >> 3) % (ksplit / 8)); 0 = off
+    int pair_ksplit, pair_nsl, pair_ncob, pair_views;
 };
 
 static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -76,7 +76,7 @@ struct DPlan {
             dc1 = b.take(pm1(h / 2, w / 2, 128)); dc0 = b.take(pm1(h, w, 64));
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
-            slab = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
+            slab = b.take((size_t)(VSR_WGRAD_NWG > VSR_WGRAD_MAX_PAIR_SLABS ? VSR_WGRAD_NWG : VSR_WGRAD_MAX_PAIR_SLABS) * stride * 4);
         }
         total = b.off;
         return VSR_OK;
@@ -143,6 +143,29 @@ struct DCtx {
             return vsr_launch_wgrad_reduce((const float*)at(p.slab), nslabs, 3, 64, 64, 64, 64, gw + (size_t)co0 * cin_total * 9, cin_total, ci0, 1, 0,
                                            nullptr, 1, st);
         return vsr_launch_wgrad_reduce_s2((const float*)at(p.slab), nslabs, stride, gw, cin_total, co0, ci0, view, st);
+    }
+    // the whole weight gradient of a wide layer: x (xC channels; views == 4: the four parity views of a 4x4 stride-2 conv's input),
+    // dy (dyC channels).  bf16: every (view, cout block, cin slice) pair in one launch + one reduction; fp32: pair by pair.
+    int wgrad_layer(const void* x, int xC, int Hx, int Wx, int views, const void* dy, int dyC, int H, int W, float* gw) const {
+        const int nsl = xC / 64, ncob = dyC / 64, npairs = nsl * ncob * views, x_step = views == 4 ? 2 : 1;
+        if (dtype == VSR_BF16 && npairs > 1) {
+            WgradArgs a = {};
+            a.N = p.n; a.H = H; a.W = W; a.nseg = 1;
+            a.x[0] = x; a.x_step = x_step; a.Hx = Hx; a.Wx = Wx; a.x_nstride = pm_image_elems(Hx, Wx, xC); a.x_ctotal = xC;
+            a.dy[0] = dy; a.dy_step = 1; a.Hy = H; a.Wy = W; a.dy_nstride = pm_image_elems(H, W, dyC); a.dy_ctotal = dyC;
+            int cp, xp, stride;
+            vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
+            a.slab = (float*)at(p.slab); a.slab_stride = stride;
+            const int tiles = p.n * cdiv(H, 8) * cdiv(W, 32);
+            int ksplit = ((512 / npairs) + 7) & ~7;                       // ~512 workgroups per launch
+            if (ksplit < 8) ksplit = 8;
+            const int cap = (tiles + 7) & ~7;
+            if (ksplit > cap) ksplit = cap;
+            return vsr_launch_wgrad_pairs(dtype, a, nsl, ncob, views, ksplit, gw, xC, st);
+        }
+        for (int v = 0; v < views; ++v) for (int o = 0; o < ncob; ++o) for (int s = 0; s < nsl; ++s)
+            CK(wgrad_block(x, xC, s, Hx, Wx, x_step, views == 4 ? v : -1, dy, dyC, o, H, W, gw, xC, 64 * o, 64 * s));
+        return VSR_OK;
     }
 };
 
@@ -233,30 +256,25 @@ int disc_backward(const DCtx& c, float* const* g, const float* img, const float*
     CK(vsr_launch_mask_pm(dt, c.at(p.G6), c.at(p.a6), c.at(p.dc6), SLOPE, (long long)n * pm_image_elems(h, w, 64), c.st));
     // ---- conv_6 (128 -> 64 at H) ----
     CK(c.wide(c.at(p.dc6), 64, h, w, 1, h, w, p.wd[6], c.at(p.du5), 128, 1, ACT_NONE));
-    if (g[7]) for (int s = 0; s < 2; ++s) CK(c.wgrad_block(c.at(p.u5), 128, s, h, w, 1, -1, c.at(p.dc6), 64, 0, h, w, g[7], 128, 0, 64 * s));
+    if (g[7]) CK(c.wgrad_layer(c.at(p.u5), 128, h, w, 1, c.at(p.dc6), 64, h, w, g[7]));
     CK(vsr_launch_up2_bwd(dt, c.at(p.du5), c.at(p.ds5), c.at(p.dc5), c.at(p.a5), SLOPE, n, h / 2, w / 2, 128, c.st));
     // ---- conv_5 (256 -> 128 at H/2) ----
     CK(c.wide(c.at(p.dc5), 128, h / 2, w / 2, 1, h / 2, w / 2, p.wd[5], c.at(p.du4), 256, 1, ACT_NONE));
-    if (g[6]) for (int o = 0; o < 2; ++o) for (int s = 0; s < 4; ++s)
-        CK(c.wgrad_block(c.at(p.u4), 256, s, h / 2, w / 2, 1, -1, c.at(p.dc5), 128, o, h / 2, w / 2, g[6], 256, 64 * o, 64 * s));
+    if (g[6]) CK(c.wgrad_layer(c.at(p.u4), 256, h / 2, w / 2, 1, c.at(p.dc5), 128, h / 2, w / 2, g[6]));
     CK(vsr_launch_up2_bwd(dt, c.at(p.du4), c.at(p.ds4), c.at(p.dc4), c.at(p.a4), SLOPE, n, h / 4, w / 4, 256, c.st));
     // ---- conv_4 (512 -> 256 at H/4) ----
     CK(c.wide(c.at(p.dc4), 256, h / 4, w / 4, 1, h / 4, w / 4, p.wd[4], c.at(p.du3), 512, 1, ACT_NONE));
-    if (g[5]) for (int o = 0; o < 4; ++o) for (int s = 0; s < 8; ++s)
-        CK(c.wgrad_block(c.at(p.u3), 512, s, h / 4, w / 4, 1, -1, c.at(p.dc4), 256, o, h / 4, w / 4, g[5], 512, 64 * o, 64 * s));
+    if (g[5]) CK(c.wgrad_layer(c.at(p.u3), 512, h / 4, w / 4, 1, c.at(p.dc4), 256, h / 4, w / 4, g[5]));
     CK(vsr_launch_up2_bwd(dt, c.at(p.du3), nullptr, c.at(p.dc3), c.at(p.f3), SLOPE, n, h / 8, w / 8, 512, c.st));
     // ---- conv_3 (256 -> 512, 4x4 stride 2): d c2 = (dgrad + d s4) * LeakyReLU'(f2) ----
     CK(c.wide(c.at(p.dc3), 512, h / 8, w / 8, 1, h / 8, w / 8, p.wd[3], c.at(p.dc2), 256, 2, ACT_NONE, nullptr, c.at(p.ds4), nullptr, c.at(p.f2)));
-    if (g[4]) for (int v = 0; v < 4; ++v) for (int o = 0; o < 8; ++o) for (int s = 0; s < 4; ++s)
-        CK(c.wgrad_block(c.at(p.f2), 256, s, h / 4, w / 4, 2, v, c.at(p.dc3), 512, o, h / 8, w / 8, g[4], 256, 64 * o, 64 * s));
+    if (g[4]) CK(c.wgrad_layer(c.at(p.f2), 256, h / 4, w / 4, 4, c.at(p.dc3), 512, h / 8, w / 8, g[4]));
     // ---- conv_2 (128 -> 256) ----
     CK(c.wide(c.at(p.dc2), 256, h / 4, w / 4, 1, h / 4, w / 4, p.wd[2], c.at(p.dc1), 128, 2, ACT_NONE, nullptr, c.at(p.ds5), nullptr, c.at(p.f1)));
-    if (g[3]) for (int v = 0; v < 4; ++v) for (int o = 0; o < 4; ++o) for (int s = 0; s < 2; ++s)
-        CK(c.wgrad_block(c.at(p.f1), 128, s, h / 2, w / 2, 2, v, c.at(p.dc2), 256, o, h / 4, w / 4, g[3], 128, 64 * o, 64 * s));
+    if (g[3]) CK(c.wgrad_layer(c.at(p.f1), 128, h / 2, w / 2, 4, c.at(p.dc2), 256, h / 4, w / 4, g[3]));
     // ---- conv_1 (64 -> 128) ----
     CK(c.wide(c.at(p.dc1), 128, h / 2, w / 2, 1, h / 2, w / 2, p.wd[1], c.at(p.dc0), 64, 2, ACT_NONE, nullptr, c.at(p.G6), nullptr, c.at(p.f0)));
-    if (g[2]) for (int v = 0; v < 4; ++v) for (int o = 0; o < 2; ++o)
-        CK(c.wgrad_block(c.at(p.f0), 64, 0, h, w, 2, v, c.at(p.dc1), 128, o, h / 2, w / 2, g[2], 64, 64 * o, 0));
+    if (g[2]) CK(c.wgrad_layer(c.at(p.f0), 64, h, w, 4, c.at(p.dc1), 128, h / 2, w / 2, g[2]));
     // ---- conv_0 (3 -> 64 on the planar image) ----
     if (g[0]) {
         WgradArgs a = {};

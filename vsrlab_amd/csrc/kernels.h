@@ -63,4 +63,6 @@ int vsr_launch_up2_bwd(int dtype, const void* dout, void* din, void* dmask, cons
 int vsr_launch_mask_pm(int dtype, const void* g, const void* m, void* out, float slope, long long elems, hipStream_t st);
 int vsr_launch_add_pm(int dtype, const void* a, const void* b, void* out, long long elems, hipStream_t st);
 
+#define VSR_WGRAD_MAX_PAIR_SLABS 1024   // pair-batched wgrad launches: (view, cout block, cin slice) pairs x pixel parts
+int vsr_launch_wgrad_pairs(int dtype, const WgradArgs& a, int nsl, int ncob, int views, int ksplit, float* gw, int cin_total, hipStream_t st);
 #define VSR_WGRAD_NWG 512   // persistent wgrad workgroups: 2 per CU x 256 CUs

@@ -13,7 +13,7 @@
 // (gridDim x 147 KB) small against the activations streamed (t x 132 MB for a 540p trunk conv).
 // The bias gradient rides along: column sums of dY accumulated while staging dY.
 #include <cstdlib>
-#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -294,6 +294,38 @@ __global__ void wgrad_reduce_kernel(const float* slab, int nwg, int slab_stride,
     }
 }
 
+// Pair-batched launch (WgradArgs::pair_*): slab (pair * ksplit + part) holds the [9][64][64] partial of pair = (view, cout block,
+// cin slice) over the part-th pixel range.  One launch reduces every pair of a layer into its OIHW gradient (accumulating):
+//   3x3 stride-1 layer (views == 1):  gw[o*64 + co][s*64 + ci][tap]        += sum_part
+//   4x4 stride-2 layer (views == 4):  gw[o*64 + co][s*64 + ci][ky*4 + kx]  += sum_part   for the 4 taps view v owns
+//                                     ((view, d) -> k as in conv_wide.hip: view 0: k = 2 d + 1 (d in {0,1}); view 1: k = 2 (d + 1) (d in {-1,0}))
+__global__ void wgrad_reduce_pairs_kernel(const float* __restrict__ slab, int slab_stride, int ksplit, int nsl, int ncob, int views,
+                                          float* __restrict__ gw, int cin_total) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;                          // < 9 * 64 * 64 (grid.x = 576)
+    const int pair = blockIdx.y;
+    const int sl = pair % nsl, o = (pair / nsl) % ncob, v = pair / (nsl * ncob);
+    const int ci = idx & 63, co = (idx >> 6) & 63, tap = idx >> 12;
+    float* d = nullptr;
+    if (views == 1) {
+        d = gw + ((long long)(o * 64 + co) * cin_total + sl * 64 + ci) * 9 + tap;
+    } else {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int ky = (v >> 1) == 0 ? (dy >= 0 ? 2 * dy + 1 : -1) : (dy <= 0 ? 2 * (dy + 1) : -1);
+        const int kx = (v & 1) == 0 ? (dx >= 0 ? 2 * dx + 1 : -1) : (dx <= 0 ? 2 * (dx + 1) : -1);
+        if (ky >= 0 && kx >= 0) d = gw + ((long long)(o * 64 + co) * cin_total + sl * 64 + ci) * 16 + ky * 4 + kx;
+    }
+    float s = 0.f;
+    if (d) {                                                      // tap is block-uniform (4096 = 64 * 64 elements per tap)
+        const float* p = slab + (long long)pair * ksplit * slab_stride + idx;
+        for (int w = grp; w < ksplit; w += 4) s += p[(long long)w * slab_stride];
+    }
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && d) *d += (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+}
+
 template <typename T, int KS, int CX, bool XP, int COUT, bool DP>
 int launch_wgrad_inst(const WgradArgs& a0, int nwg, hipStream_t st) {
     constexpr int TWH = TW + KS - 1, THH = TH + KS - 1;
@@ -372,8 +404,24 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
     const int tiles_per_img = a.ntiles_x * a.ntiles_y;
     const int per_seg = a.N * tiles_per_img;
     const int total = a.nseg * per_seg;
-    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
-    float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+    TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
+    int x_coff = a.x_coff, dy_coff = a.dy_coff, x_oy = a.x_oy, x_ox = a.x_ox;
+    int slab_idx = blockIdx.x;
+    if (a.pair_ksplit > 0) {
+        // one launch for all 64x64 blocks of a wide layer's weight gradient: this workgroup owns pair (view, cout block,
+        // cin slice) and the part-th contiguous range of tiles; the 8 XCDs each see one eighth of the pixel ranges for ALL
+        // pairs, so a slice of a pixel range is fetched into one L2 and shared by the pairs that use it
+        const int kq = a.pair_ksplit >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int pair = j / kq, part = xcd + 8 * (j - pair * kq);
+        const int s = pair % a.pair_nsl, o = (pair / a.pair_nsl) % a.pair_ncob, v = pair / (a.pair_nsl * a.pair_ncob);
+        x_coff = s * 8; dy_coff = o * 8;
+        if (a.pair_views > 1) { x_oy = v >> 1; x_ox = v & 1; }
+        walk.first = (int)((long long)total * part / a.pair_ksplit);
+        walk.end = (int)((long long)total * (part + 1) / a.pair_ksplit);
+        walk.stride = 1;
+        slab_idx = pair * a.pair_ksplit + part;
+    }
+    float* slab = a.slab + (long long)slab_idx * a.slab_stride;
 
     if (role == 1) {
         // =================== producers ===================
@@ -391,7 +439,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 const int idx = piece * 64 + lane;
                 const int row = idx / (8 * XS), rem = idx - row * (8 * XS);
                 const int c = rem / XS, tx = rem - c * XS;
-                const int dx = (tx - 1) * a.x_step + a.x_ox;
+                const int dx = (tx - 1) * a.x_step + x_ox;
                 rel[i] = (((((row - 1) * a.x_step) * pm_ws(a.Wx) + (dx >> 5)) * xcp + c) * 256 + (dx & 31) * 8) * 2;
                 if (tx >= TW + 2) padmask |= 1u << i;
             } else {
@@ -411,8 +459,8 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
             const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
             const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
             const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
-            const char* xo = xb + pm_off(ty0 * a.x_step + a.x_oy, tx0 * a.x_step, a.x_coff, a.Wx, xcp * 8) * 2;      // tx0*step: multiple of 32
-            const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, a.dy_coff, a.Wy, ycp * 8) * 2;
+            const char* xo = xb + pm_off(ty0 * a.x_step + x_oy, tx0 * a.x_step, x_coff, a.Wx, xcp * 8) * 2;      // tx0*step: multiple of 32
+            const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, dy_coff, a.Wy, ycp * 8) * 2;
             char* lxs = smem + s * DSET;
             const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;              // wave-uniform
 #pragma unroll
@@ -624,6 +672,28 @@ int vsr_launch_wgrad_reduce(const float* slab, int nwg, int ks, int cx, int cout
     const int total = ks * ks * cout_real * cin_real + (gb ? cout_real : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, nwg, stride, ks * ks,
                        coutp, cxp, cout_real, cin_real, gw, I_total, i_off, o_mul, o_add, gb, accumulate);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+// Every 64x64 block of a wide layer's weight gradient in ONE launch of the producer / consumer kernel + ONE reduction
+// (bf16 only; a.x / a.dy describe the full tensors, the kernel derives each pair's slices and parity view).  The slab
+// must hold nsl * ncob * views * ksplit partials of slab_stride floats.
+int vsr_launch_wgrad_pairs(int dtype, const WgradArgs& a0, int nsl, int ncob, int views, int ksplit, float* gw, int cin_total, hipStream_t st) {
+    if (dtype != VSR_BF16) return VSR_ERR_UNSUPPORTED;
+    if (nsl < 1 || ncob < 1 || (views != 1 && views != 4) || ksplit < 8 || (ksplit & 7) || a0.nseg < 1 || a0.nseg > VSR_WG_MAXSEG) return VSR_ERR_BADARG;
+    const int npairs = nsl * ncob * views;
+    if ((long long)npairs * ksplit > VSR_WGRAD_MAX_PAIR_SLABS) return VSR_ERR_BADARG;
+    constexpr int LDS = 2 * DSET;
+    static VsrDevOnce once;
+    { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(wgrad3x3_c64_pc_kernel), LDS); if (rc != VSR_OK) return rc; }
+    WgradArgs a = a0;
+    a.ntiles_x = cdiv(a.W, TW);
+    a.ntiles_y = cdiv(a.H, TH);
+    a.pair_ksplit = ksplit; a.pair_nsl = nsl; a.pair_ncob = ncob; a.pair_views = views;
+    hipLaunchKernelGGL(wgrad3x3_c64_pc_kernel, dim3(npairs * ksplit), dim3(DNT), LDS, st, a);
+    HIP_CHECK_RET(hipGetLastError());
+    hipLaunchKernelGGL(wgrad_reduce_pairs_kernel, dim3(9 * 64, npairs), dim3(256), 0, st, a.slab, a.slab_stride, ksplit, nsl, ncob, views, gw, cin_total);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
