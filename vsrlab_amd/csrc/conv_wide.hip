@@ -279,6 +279,281 @@ __global__ void pack_wide_kernel(const float* __restrict__ w, T* __restrict__ ds
     dst[idx] = (T)v;
 }
 
+// =====================================================================================================================
+// conv_wide2: the bf16 kernel of the layers whose output has >= 128 channels (everything in the discriminator except
+// conv_6 forward and conv_1's data gradient).  Same implicit GEMM, built like conv3x3_persist.hip:
+//   * one 512-thread workgroup per CU, persistent over 8x32-pixel tiles of ONE output column = (output phase, 128-channel
+//     block); 8 MFMA waves = 4 pixel groups (2 tile rows) x 2 halves of 64 output channels: 64 accumulator registers,
+//     v_mfma_f32_16x16x32_bf16, fragment reads as inline-asm ds_read_b128 at base + immediate;
+//   * a STEP = one active tap of one 64-channel source slice = 32 MFMAs per wave against a 16 KiB weight slab
+//     [128 rows][64 k], which arrives by LDS-DMA two steps ahead into a ring of three buffers; the haloed 10x34 tile of
+//     the NEXT source (slice / parity view, or the next tile's first source) is DMA'd into the other of two 42.5 KiB
+//     tile buffers during the first step of the current one.  The weights are packed in execution order with the LDS
+//     swizzle already applied (pack_wide2_kernel), so a slab is a linear 16 KiB copy and masked taps do not exist;
+//   * one s_barrier per step (2 waves per SIMD x 32 MFMAs = 1024 matrix-core cycles between barriers) with COUNTED vmcnt
+//     waits: at the end of step K only W(K+1) has to be in LDS, so the 2 (+5..6 tile) youngest DMA requests stay in flight.
+//     hipcc does not see the inline-asm reads as LDS accesses, so it inserts no alias waits of its own.
+//   * stores of an epilogue may complete out of order with loads, so the kernel drains vmcnt before an epilogue and once,
+//     one step later, after it; in between nothing is needed that is not already in LDS.
+constexpr int W2_NT = 512;
+constexpr int W2_WSLAB = 128 * 64 * 2;                 // 16,384 B
+constexpr int W2_TILE = NPIX * 128;                    // 43,520 B
+constexpr int W2_LDS = 3 * W2_WSLAB + 2 * W2_TILE;     // 136,192 B
+constexpr int W2_CHUNKS = NPIX * 8;                    // 2,720 16-byte chunks per tile
+constexpr int W2_NPIECE = (W2_CHUNKS + 63) / 64;       // 43 DMA pieces of 1 KiB
+constexpr int W2_TPW = (W2_NPIECE + 7) / 8;            // 6 per wave (waves 3..7: 5)
+
+struct Wide2Args {
+    const void* x; long long x_nstride; int xCP, Hx, Wx, in_step, nsl, nsrc;
+    int N, H, W;
+    const void* wpack; int nsteps;
+    unsigned tapmask[4];
+    const float* bias;
+    void* y; long long y_nstride; int yCP, Hy, Wy, out_step, ncp;
+    int act; float slope; const void* res; const void* aux;
+};
+
+__device__ uint4 g_w2_zero_chunk[1];
+
+#define W2_GLDS16(src, dst)                                                                           \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+struct __attribute__((aligned(8))) w2bf4 { bf16_t v[4]; };
+
+__global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, ch = wave >> 2;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int pxl = (l15 >= 4 && l15 < 12) ? 2 * (l15 - 4) : (l15 < 4 ? 2 * l15 + 1 : 2 * (l15 - 8) + 1);   // as conv3x3_persist
+    char* lds_w = smem;
+    char* lds_t = smem + 3 * W2_WSLAB;
+
+    const int col = blockIdx.y, cp = col % a.ncp, oph = col / a.ncp;
+    const int ntx = cdiv(a.W, TW), nty = cdiv(a.H, TH), per_img = ntx * nty, total = a.N * per_img;
+    const int my_tiles = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (my_tiles == 0) return;
+    const long long Ktot = (long long)my_tiles * a.nsteps;
+    const char* wcol = reinterpret_cast<const char*>(a.wpack) + (long long)col * a.nsteps * W2_WSLAB;
+    const int WSx = pm_ws(a.Wx), WSy = pm_ws(a.Wy);
+    const char* zsrc = reinterpret_cast<const char*>(g_w2_zero_chunk);
+
+    // tile DMA: piece = wave + 8 i, LDS slot = [row ty][chunk c][34 pixels tx] x 16 B (the image conv3x3_persist uses)
+    int rel[W2_TPW];
+#pragma unroll
+    for (int i = 0; i < W2_TPW; ++i) {
+        const int idx = (wave + 8 * i) * 64 + lane;
+        const int ty = idx / (8 * TWH), rem = idx - ty * (8 * TWH);
+        const int c = rem / TWH, tx = rem - c * TWH;
+        const int dx = (tx - 1) * a.in_step;
+        rel[i] = (((((ty - 1) * a.in_step) * WSx + (dx >> 5)) * a.xCP + c) * 256 + (dx & 31) * 8) * 2;
+    }
+    auto issue_tile = [&](int tile, int s, int buf) {
+        const int n = tile / per_img, r = tile - n * per_img;
+        const int ty0 = (r / ntx) * TH, tx0 = (r % ntx) * TW;
+        const int slice = s % a.nsl, view = s / a.nsl;
+        const int oy = a.in_step == 2 ? (view >> 1) : 0, ox = a.in_step == 2 ? (view & 1) : 0;
+        const char* org = reinterpret_cast<const char*>(a.x) +
+            ((long long)n * a.x_nstride + (((long long)(ty0 * a.in_step + oy) * WSx + ((tx0 * a.in_step) >> 5)) * a.xCP + slice * 8) * 256 + ox * 8) * 2;
+        char* dstb = lds_t + buf * W2_TILE;
+        const bool interior = ty0 >= 1 && ty0 + TH < a.H && tx0 >= 1 && tx0 + TW < a.W;
+#pragma unroll
+        for (int i = 0; i < W2_TPW; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece < W2_NPIECE) {
+                const int idx = piece * 64 + lane;
+                const char* src = org + rel[i];
+                if (!interior) {
+                    const int ty = idx / (8 * TWH), tx = (idx - ty * (8 * TWH)) % TWH;
+                    const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+                    if (!(vy >= 0 && vy < a.H && vx >= 0 && vx < a.W)) src = zsrc;
+                }
+                if (idx < W2_CHUNKS) W2_GLDS16(src, dstb + piece * 1024);
+            }
+        }
+    };
+    auto issue_w = [&](int kmod, int wb) {
+        const char* src = wcol + (long long)kmod * W2_WSLAB + lane * 16;
+        char* dst = lds_w + wb * W2_WSLAB;
+        W2_GLDS16(src + wave * 1024, dst + wave * 1024);
+        W2_GLDS16(src + (wave + 8) * 1024, dst + (wave + 8) * 1024);
+    };
+
+    // A (weights) lane base: row ch*64 + 16 mb + l15 of the slab, chunk (4 kk + q) ^ ((row >> 1) & 7); B (pixels) lane base as persist
+    unsigned a_lane[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_lane[kk] = (unsigned)(((ch * 64 + l15) * 8 + ((4 * kk + q) ^ ((l15 >> 1) & 7))) * 16);
+    const unsigned b_lane = (unsigned)(3 * W2_WSLAB + pg * 2 * (TWH * 128) + q * (TWH * 16) + pxl * 16);
+
+    // ---- prologue: first tile's first source, W(0), W(1) ----
+    int tile = blockIdx.x;
+    issue_tile(tile, 0, 0);
+    issue_w(0, 0);
+    if (Ktot > 1) issue_w(1 % a.nsteps, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    long long K = 0;
+    int wbi = 0;                       // K % 3
+    int k2 = 2 % a.nsteps, wb2 = 2;    // (K + 2) % nsteps, (K + 2) % 3
+    int tb = 0;
+    int post_epi = 2;                  // 2: first step after a drain (nothing to wait for), 1: drain again (stores), 0: counted waits
+    bool prev_tile_dma = false;
+
+    for (int t = 0; t < my_tiles; ++t, tile += gridDim.x) {
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cp * 128 + ch * 64 + mb * 16 + 4 * q);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) { acc[mb][nb][0] = bv.x; acc[mb][nb][1] = bv.y; acc[mb][nb][2] = bv.z; acc[mb][nb][3] = bv.w; }
+        }
+        for (int s = 0; s < a.nsrc; ++s) {
+            const unsigned mask = a.tapmask[a.in_step == 2 ? s / a.nsl : oph];
+            const bool last_src = s + 1 == a.nsrc;
+            const bool has_next = !last_src || t + 1 < my_tiles;
+            bool first = true;
+            const unsigned bb = b_lane + (unsigned)(tb * W2_TILE);
+            bf16x8_t fa[2][4], fb[2][4];
+#define W2_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define W2_LOADA(kk_, slot) { W2_DSR(fa[slot][0], ab[kk_], 0); W2_DSR(fa[slot][1], ab[kk_], 2048); W2_DSR(fa[slot][2], ab[kk_], 4096); W2_DSR(fa[slot][3], ab[kk_], 6144); }
+#define W2_LOADB1(ky_, kx_, kk_, slot, nb) W2_DSR(fb[slot][nb], bb, (((nb) >> 1) + ky_) * (TWH * 128) + kk_ * (4 * TWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
+#define W2_LOADB(ky_, kx_, kk_, slot) { W2_LOADB1(ky_, kx_, kk_, slot, 0) W2_LOADB1(ky_, kx_, kk_, slot, 1) W2_LOADB1(ky_, kx_, kk_, slot, 2) W2_LOADB1(ky_, kx_, kk_, slot, 3) }
+#define W2_MFMA(slot, mb, nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][mb], fb[slot][nb], acc[mb][nb], 0, 0, 0);
+#define W2_MFMA_ROW(slot, mb) W2_MFMA(slot, mb, 0) W2_MFMA(slot, mb, 1) W2_MFMA(slot, mb, 2) W2_MFMA(slot, mb, 3)
+#define W2_STEP(tap_)                                                                                                   \
+            if (mask & (1u << (tap_))) {                                                                                \
+                constexpr int ky_ = (tap_) / 3, kx_ = (tap_) % 3;                                                       \
+                const bool w_issued = K + 2 < Ktot;                                                                     \
+                if (w_issued) issue_w(k2, wb2);                                                                         \
+                const bool t_issued = first && has_next;                                                                \
+                if (t_issued) { if (last_src) issue_tile(tile + gridDim.x, 0, tb ^ 1); else issue_tile(tile, s + 1, tb ^ 1); } \
+                unsigned ab[2];                                                                                         \
+                ab[0] = a_lane[0] + (unsigned)(wbi * W2_WSLAB); ab[1] = a_lane[1] + (unsigned)(wbi * W2_WSLAB);         \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_LOADA(0, 0) W2_LOADB(ky_, kx_, 0, 0)                                                                 \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_MFMA_ROW(0, 0)                                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_LOADA(1, 1)                                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_MFMA_ROW(0, 1)                                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_LOADB(ky_, kx_, 1, 1)                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_MFMA_ROW(0, 2) W2_MFMA_ROW(0, 3)                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                W2_MFMA_ROW(1, 0) W2_MFMA_ROW(1, 1) W2_MFMA_ROW(1, 2) W2_MFMA_ROW(1, 3)                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                if (post_epi == 2) { post_epi = 1; }                                                                    \
+                else if (post_epi == 1 || !w_issued) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); post_epi = 0; } \
+                else if (t_issued || prev_tile_dma) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }                \
+                else { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                                               \
+                __builtin_amdgcn_s_barrier();                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                prev_tile_dma = t_issued;                                                                               \
+                first = false;                                                                                          \
+                ++K; wbi = wbi == 2 ? 0 : wbi + 1; wb2 = wb2 == 2 ? 0 : wb2 + 1; k2 = k2 + 1 == a.nsteps ? 0 : k2 + 1;  \
+            }
+            W2_STEP(0) W2_STEP(1) W2_STEP(2) W2_STEP(3) W2_STEP(4) W2_STEP(5) W2_STEP(6) W2_STEP(7) W2_STEP(8)
+#undef W2_STEP
+#undef W2_MFMA_ROW
+#undef W2_MFMA
+#undef W2_LOADB
+#undef W2_LOADB1
+#undef W2_LOADA
+#undef W2_DSR
+            tb ^= 1;
+        }
+        // ---- epilogue: drain the DMA queue first (see the header), then registers -> blocked layout, 8-byte stores ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        post_epi = 2;
+        prev_tile_dma = false;
+        {
+            const int n = tile / per_img, r = tile - n * per_img;
+            const int ty0 = (r / ntx) * TH, tx0 = (r % ntx) * TW;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int vy = ty0 + 2 * pg + (nb >> 1), vx = tx0 + (nb & 1) * 16 + pxl;
+                if (vy < a.H && vx < a.W) {
+                    const int oyy = vy * a.out_step + (a.out_step == 2 ? (oph >> 1) : 0);
+                    const int oxx = vx * a.out_step + (a.out_step == 2 ? (oph & 1) : 0);
+                    const long long pix = (long long)n * a.y_nstride + (((long long)oyy * WSy + (oxx >> 5)) * a.yCP + cp * 16 + ch * 8) * 256 + (oxx & 31) * 8;
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const long long o = pix + (2 * mb + (q >> 1)) * 256 + 4 * (q & 1);
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[mb][nb][j];
+                        if (a.act == ACT_LEAKY) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : a.slope * v[j];
+                        } else if (a.act == ACT_RELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                        }
+                        if (a.res) {
+                            const w2bf4 rr = *reinterpret_cast<const w2bf4*>(reinterpret_cast<const bf16_t*>(a.res) + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)rr.v[j];
+                        }
+                        if (a.aux) {
+                            const w2bf4 mm = *reinterpret_cast<const w2bf4*>(reinterpret_cast<const bf16_t*>(a.aux) + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mm.v[j] > 0.f ? 1.f : a.slope);
+                        }
+                        w2bf4 out;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) out.v[j] = (bf16_t)v[j];
+                        *reinterpret_cast<w2bf4*>(reinterpret_cast<bf16_t*>(a.y) + o) = out;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Weight image of conv_wide2: [column = ophase * ncp + cp][step k][128 rows][8 chunks of 8, chunk c stored at c ^ ((row >> 1) & 7)],
+// steps in execution order: source (view-major, then slice), then the ACTIVE taps of that source in increasing tap index.
+// Modes as pack_wide_kernel.
+template <typename T>
+__global__ void pack_wide2_kernel(const float* __restrict__ w, T* __restrict__ dst, int cout, int cin, int mode, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = (int)(idx & 7), cs = (int)((idx >> 3) & 7), r = (int)((idx >> 6) & 127);
+    long long rest = idx >> 13;
+    const bool s2 = mode == 1 || mode == 3;
+    const int tps = s2 ? 4 : 9;
+    const int nsl = (mode == 0 || mode == 1 ? cin : cout) / 64, nviews = mode == 1 ? 4 : 1;
+    const int rows = (mode == 0 || mode == 1) ? cout : cin, ncp = rows / 128;
+    const int nsteps = nsl * nviews * tps;
+    const int k = (int)(rest % nsteps), col = (int)(rest / nsteps);
+    const int cp = col % ncp, oph = col / ncp;
+    const int src = k / tps, j = k - src * tps;
+    const int slice = src % nsl, view = src / nsl;
+    const int ci = ((cs ^ ((r >> 1) & 7)) << 3) + e;
+    const int row = cp * 128 + r, colc = slice * 64 + ci;
+    float v;
+    if (mode == 0) {
+        v = w[((long long)row * cin + colc) * 9 + j];
+    } else if (mode == 2) {
+        v = w[((long long)colc * cin + row) * 9 + (8 - j)];
+    } else if (mode == 1) {
+        const int dy = ((view >> 1) ? -1 : 0) + (j >> 1), dx = ((view & 1) ? -1 : 0) + (j & 1);
+        v = w[((long long)row * cin + colc) * 16 + s2_fwd_k(view >> 1, dy) * 4 + s2_fwd_k(view & 1, dx)];
+    } else {
+        const int dy = ((oph >> 1) ? 0 : -1) + (j >> 1), dx = ((oph & 1) ? 0 : -1) + (j & 1);
+        v = w[((long long)colc * cin + row) * 16 + s2_bwd_k(oph >> 1, dy) * 4 + s2_bwd_k(oph & 1, dx)];
+    }
+    dst[idx] = (T)v;
+}
+
 // Partial slabs of a 3x3 weight gradient taken on parity view `view` of a 4x4 stride-2 conv's input -> the 4x4 OIHW gradient
 // (accumulated): gw[co0 + co][ci0 + ci][ky][kx] += sum_wg slab[wg][tap][co][ci] for the 4 taps the view owns.
 __global__ void wgrad_reduce_s2_kernel(const float* __restrict__ slab, int nwg, int slab_stride, float* __restrict__ gw, int cin_total,
@@ -533,7 +808,7 @@ inline int wgrid(long long total, int block = 256) {
 
 // ======================================= host side (C++ linkage, used by disc_engine.hip) ==================================
 int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st) {
-    if (!c.x || !c.y || !c.wpack || c.N < 1 || c.H < 1 || c.W < 1 || c.nsl < 1 || c.ncob < 1) return VSR_ERR_BADARG;
+    if (!c.x || !c.y || (!c.wpack && !c.wpack2) || c.N < 1 || c.H < 1 || c.W < 1 || c.nsl < 1 || c.ncob < 1) return VSR_ERR_BADARG;
     if ((c.xC & 63) || (c.yC & 63) || c.nsl * 64 > c.xC || c.ncob * 64 > c.yC) return VSR_ERR_BADARG;
     if ((c.in_step != 1 && c.in_step != 2) || (c.out_step != 1 && c.out_step != 2) || (c.in_step == 2 && c.out_step == 2)) return VSR_ERR_BADARG;
     WideArgs a = {};
@@ -552,6 +827,28 @@ int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st) {
     }
     a.act = c.act; a.slope = c.slope; a.y_act = c.y_act; a.res = c.res; a.y_pre = c.y_pre; a.aux = c.aux;
     const int nph = c.out_step == 2 ? 4 : 1;
+    if (c.wpack2) {                                  // bf16, >= 128 output channels: the DMA-fed persistent kernel
+        if (dtype != VSR_BF16 || (c.ncob & 1) || c.y_act || c.y_pre) return VSR_ERR_BADARG;
+        Wide2Args b = {};
+        b.x = c.x; b.x_nstride = a.x_nstride; b.xCP = c.xC >> 3; b.Hx = c.Hx; b.Wx = c.Wx; b.in_step = c.in_step; b.nsl = c.nsl;
+        b.nsrc = c.nsl * (c.in_step == 2 ? 4 : 1);
+        b.N = c.N; b.H = c.H; b.W = c.W; b.wpack = c.wpack2;
+        b.nsteps = b.nsrc * ((c.in_step == 2 || c.out_step == 2) ? 4 : 9);
+        for (int i = 0; i < 4; ++i) b.tapmask[i] = a.tapmask[i];
+        b.bias = c.bias; b.y = c.y; b.y_nstride = a.y_nstride; b.yCP = c.yC >> 3; b.Hy = c.Hy; b.Wy = c.Wy; b.out_step = c.out_step;
+        b.ncp = c.ncob / 2; b.act = c.act; b.slope = c.slope; b.res = c.res; b.aux = c.aux;
+        const int cols = b.ncp * nph;
+        const int tiles = c.N * cdiv(c.H, TH) * cdiv(c.W, TW);
+        int nwx = vsr_num_cus() / cols;
+        if (nwx < 1) nwx = 1;
+        if (nwx > tiles) nwx = tiles;
+        static VsrDevOnce once2;
+        { const int rc = vsr_set_max_dynamic_lds(once2, reinterpret_cast<const void*>(conv_wide2_kernel), W2_LDS); if (rc != VSR_OK) return rc; }
+        hipLaunchKernelGGL(conv_wide2_kernel, dim3(nwx, cols), dim3(W2_NT), W2_LDS, st, b);
+        HIP_CHECK_RET(hipGetLastError());
+        return VSR_OK;
+    }
+    if (!c.wpack) return VSR_ERR_BADARG;
     const long long gz = (long long)c.N * nph * c.ncob;
     if (gz > 65535) return VSR_ERR_UNSUPPORTED;
     dim3 grid(cdiv(c.W, TW), cdiv(c.H, TH), (unsigned)gz);
@@ -582,6 +879,22 @@ int vsr_launch_pack_wide(int dtype, const float* w, void* dst, int cout, int cin
     if (dtype == VSR_BF16) hipLaunchKernelGGL(pack_wide_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)dst, cout, cin, mode, total);
     else if (dtype == VSR_F32) hipLaunchKernelGGL(pack_wide_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)dst, cout, cin, mode, total);
     else return VSR_ERR_BADARG;
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+long long vsr_wide2_pack_elems(int cout, int cin, int mode) {
+    const bool s2 = mode == 1 || mode == 3;
+    const int nsl = (mode == 0 || mode == 1 ? cin : cout) / 64, rows = (mode == 0 || mode == 1) ? cout : cin;
+    const long long cols = (long long)(rows / 128) * (mode == 3 ? 4 : 1);
+    return cols * nsl * (mode == 1 ? 4 : 1) * (s2 ? 4 : 9) * 8192;
+}
+
+int vsr_launch_pack_wide2(const float* w, void* dst, int cout, int cin, int mode, hipStream_t st) {
+    const int rows = (mode == 0 || mode == 1) ? cout : cin;
+    if (!w || !dst || (cout & 63) || (cin & 63) || (rows & 127) || mode < 0 || mode > 3) return VSR_ERR_BADARG;
+    const long long total = vsr_wide2_pack_elems(cout, cin, mode);
+    hipLaunchKernelGGL(pack_wide2_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (bf16_t*)dst, cout, cin, mode, total);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

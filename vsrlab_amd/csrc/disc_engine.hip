@@ -37,7 +37,8 @@ struct DPlan {
     int n, h, w, dtype; size_t es;
     // packed weights
     size_t w0, b0, w0d, w9, b9, w9d, w7, w7d, w8, w8d;
-    size_t wf[7], wd[7];                 // conv_1 .. conv_6 forward / data-gradient packs (index k-1)
+    size_t wf[7], wd[7];                 // conv_1 .. conv_6 forward / data-gradient packs
+    bool fw2[7], dw2[7];                   // ... in conv_wide2's image
     // activations
     size_t f0, f1, f2, f3, u3, a4, u4, a5, u5, a6, s6, o7, o8;
     // backward scratch
@@ -59,8 +60,11 @@ struct DPlan {
         const int co[7] = {0, 128, 256, 512, 256, 128, 64}, ci[7] = {0, 64, 128, 256, 512, 256, 128};
         for (int k = 1; k <= 6; ++k) {
             const bool s2 = k <= 3;
-            wf[k] = b.take((size_t)vsr_wide_pack_elems(co[k], ci[k], s2 ? 1 : 0) * es);
-            wd[k] = b.take((size_t)vsr_wide_pack_elems(co[k], ci[k], s2 ? 3 : 2) * es);
+            // bf16 layers with >= 128 output channels run on conv_wide2 (its own weight image): forward rows = cout, dgrad rows = cin
+            fw2[k] = dtype == VSR_BF16 && (co[k] & 127) == 0;
+            dw2[k] = dtype == VSR_BF16 && (ci[k] & 127) == 0;
+            wf[k] = b.take((size_t)(fw2[k] ? vsr_wide2_pack_elems(co[k], ci[k], s2 ? 1 : 0) : vsr_wide_pack_elems(co[k], ci[k], s2 ? 1 : 0)) * es);
+            wd[k] = b.take((size_t)(dw2[k] ? vsr_wide2_pack_elems(co[k], ci[k], s2 ? 3 : 2) : vsr_wide_pack_elems(co[k], ci[k], s2 ? 3 : 2)) * es);
         }
         f0 = b.take(pm(h, w, 64)); f1 = b.take(pm(h / 2, w / 2, 128)); f2 = b.take(pm(h / 4, w / 4, 256)); f3 = b.take(pm(h / 8, w / 8, 512));
         u3 = b.take(pm(h / 4, w / 4, 512)); a4 = b.take(pm(h / 4, w / 4, 256)); u4 = b.take(pm(h / 2, w / 2, 256));
@@ -114,11 +118,12 @@ struct DCtx {
         a.src[0] = x; a.wpack = at(wpack); a.dst[0] = y; a.act = act; a.aux[0] = aux; a.mask_mode = mask;
         return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
     }
-    int wide(const void* x, int xC, int Hx, int Wx, int in_step, int H, int W, size_t wpack, void* y, int yC, int out_step, int act,
+    int wide(const void* x, int xC, int Hx, int Wx, int in_step, int H, int W, size_t wpack, bool w2, void* y, int yC, int out_step, int act,
              void* y_act = nullptr, const void* res = nullptr, void* y_pre = nullptr, const void* aux = nullptr) const {
         VsrWideConv c = {};
         c.x = x; c.xC = xC; c.Hx = Hx; c.Wx = Wx; c.in_step = in_step; c.nsl = xC / 64;
-        c.N = p.n; c.H = H; c.W = W; c.wpack = at(wpack); c.bias = nullptr;
+        c.N = p.n; c.H = H; c.W = W; c.bias = nullptr;
+        if (w2) c.wpack2 = at(wpack); else c.wpack = at(wpack);
         c.y = y; c.yC = yC; c.Hy = H * out_step; c.Wy = W * out_step; c.out_step = out_step; c.ncob = yC / 64;
         c.act = act; c.slope = SLOPE; c.y_act = y_act; c.res = res; c.y_pre = y_pre; c.aux = aux;
         return vsr_launch_conv_wide(dtype, c, st);
@@ -179,8 +184,12 @@ int disc_pack(const DCtx& c, const float* const* prm, bool bwd) {
     const int co[7] = {0, 128, 256, 512, 256, 128, 64}, ci[7] = {0, 64, 128, 256, 512, 256, 128};
     for (int k = 1; k <= 6; ++k) {
         const bool s2 = k <= 3;
-        CK(vsr_launch_pack_wide(dt, prm[1 + k], c.at(p.wf[k]), co[k], ci[k], s2 ? 1 : 0, c.st));
-        if (bwd) CK(vsr_launch_pack_wide(dt, prm[1 + k], c.at(p.wd[k]), co[k], ci[k], s2 ? 3 : 2, c.st));
+        if (p.fw2[k]) CK(vsr_launch_pack_wide2(prm[1 + k], c.at(p.wf[k]), co[k], ci[k], s2 ? 1 : 0, c.st));
+        else CK(vsr_launch_pack_wide(dt, prm[1 + k], c.at(p.wf[k]), co[k], ci[k], s2 ? 1 : 0, c.st));
+        if (bwd) {
+            if (p.dw2[k]) CK(vsr_launch_pack_wide2(prm[1 + k], c.at(p.wd[k]), co[k], ci[k], s2 ? 3 : 2, c.st));
+            else CK(vsr_launch_pack_wide(dt, prm[1 + k], c.at(p.wd[k]), co[k], ci[k], s2 ? 3 : 2, c.st));
+        }
     }
     CK(vsr_launch_pack_weights(dt, prm[8], c.at(p.w7), 9, C, C, C, C, C, 0, 1, 0, 0, c.st));
     CK(vsr_launch_pack_weights(dt, prm[9], c.at(p.w8), 9, C, C, C, C, C, 0, 1, 0, 0, c.st));
@@ -203,15 +212,15 @@ int disc_forward(const DCtx& c, const float* img, float* out) {
         a.src[0] = img; a.src_nstride[0] = (long long)3 * h * w; a.wpack = c.at(p.w0); a.bias = c.fat(p.b0); a.dst[0] = c.at(p.f0); a.act = ACT_LEAKY;
         CK(vsr_launch_conv(dt, 3, 1, 16, 16, 1, 64, EPI_NHWC, a, c.st));
     }
-    CK(c.wide(c.at(p.f0), 64, h, w, 2, h / 2, w / 2, p.wf[1], c.at(p.f1), 128, 1, ACT_LEAKY));
-    CK(c.wide(c.at(p.f1), 128, h / 2, w / 2, 2, h / 4, w / 4, p.wf[2], c.at(p.f2), 256, 1, ACT_LEAKY));
-    CK(c.wide(c.at(p.f2), 256, h / 4, w / 4, 2, h / 8, w / 8, p.wf[3], c.at(p.f3), 512, 1, ACT_LEAKY));
+    CK(c.wide(c.at(p.f0), 64, h, w, 2, h / 2, w / 2, p.wf[1], p.fw2[1], c.at(p.f1), 128, 1, ACT_LEAKY));
+    CK(c.wide(c.at(p.f1), 128, h / 2, w / 2, 2, h / 4, w / 4, p.wf[2], p.fw2[2], c.at(p.f2), 256, 1, ACT_LEAKY));
+    CK(c.wide(c.at(p.f2), 256, h / 4, w / 4, 2, h / 8, w / 8, p.wf[3], p.fw2[3], c.at(p.f3), 512, 1, ACT_LEAKY));
     CK(vsr_launch_up2_fwd(dt, c.at(p.f3), nullptr, c.at(p.u3), n, h / 8, w / 8, 512, c.st));
-    CK(c.wide(c.at(p.u3), 512, h / 4, w / 4, 1, h / 4, w / 4, p.wf[4], c.at(p.a4), 256, 1, ACT_LEAKY));
+    CK(c.wide(c.at(p.u3), 512, h / 4, w / 4, 1, h / 4, w / 4, p.wf[4], p.fw2[4], c.at(p.a4), 256, 1, ACT_LEAKY));
     CK(vsr_launch_up2_fwd(dt, c.at(p.a4), c.at(p.f2), c.at(p.u4), n, h / 4, w / 4, 256, c.st));
-    CK(c.wide(c.at(p.u4), 256, h / 2, w / 2, 1, h / 2, w / 2, p.wf[5], c.at(p.a5), 128, 1, ACT_LEAKY));
+    CK(c.wide(c.at(p.u4), 256, h / 2, w / 2, 1, h / 2, w / 2, p.wf[5], p.fw2[5], c.at(p.a5), 128, 1, ACT_LEAKY));
     CK(vsr_launch_up2_fwd(dt, c.at(p.a5), c.at(p.f1), c.at(p.u5), n, h / 2, w / 2, 128, c.st));
-    CK(c.wide(c.at(p.u5), 128, h, w, 1, h, w, p.wf[6], c.at(p.s6), 64, 1, ACT_LEAKY, c.at(p.a6), c.at(p.f0)));
+    CK(c.wide(c.at(p.u5), 128, h, w, 1, h, w, p.wf[6], p.fw2[6], c.at(p.s6), 64, 1, ACT_LEAKY, c.at(p.a6), c.at(p.f0)));
     CK(c.conv64(c.at(p.s6), p.w7, c.at(p.o7), ACT_LEAKY, nullptr, 0));
     CK(c.conv64(c.at(p.o7), p.w8, c.at(p.o8), ACT_LEAKY, nullptr, 0));
     {   // conv_9: 64 -> 1 logits, planar fp32
@@ -255,25 +264,25 @@ int disc_backward(const DCtx& c, float* const* g, const float* img, const float*
     if (g[8]) CK(c.wgrad_block(c.at(p.s6), 64, 0, h, w, 1, -1, c.at(p.d_o7), 64, 0, h, w, g[8], 64, 0, 0));
     CK(vsr_launch_mask_pm(dt, c.at(p.G6), c.at(p.a6), c.at(p.dc6), SLOPE, (long long)n * pm_image_elems(h, w, 64), c.st));
     // ---- conv_6 (128 -> 64 at H) ----
-    CK(c.wide(c.at(p.dc6), 64, h, w, 1, h, w, p.wd[6], c.at(p.du5), 128, 1, ACT_NONE));
+    CK(c.wide(c.at(p.dc6), 64, h, w, 1, h, w, p.wd[6], p.dw2[6], c.at(p.du5), 128, 1, ACT_NONE));
     if (g[7]) CK(c.wgrad_layer(c.at(p.u5), 128, h, w, 1, c.at(p.dc6), 64, h, w, g[7]));
     CK(vsr_launch_up2_bwd(dt, c.at(p.du5), c.at(p.ds5), c.at(p.dc5), c.at(p.a5), SLOPE, n, h / 2, w / 2, 128, c.st));
     // ---- conv_5 (256 -> 128 at H/2) ----
-    CK(c.wide(c.at(p.dc5), 128, h / 2, w / 2, 1, h / 2, w / 2, p.wd[5], c.at(p.du4), 256, 1, ACT_NONE));
+    CK(c.wide(c.at(p.dc5), 128, h / 2, w / 2, 1, h / 2, w / 2, p.wd[5], p.dw2[5], c.at(p.du4), 256, 1, ACT_NONE));
     if (g[6]) CK(c.wgrad_layer(c.at(p.u4), 256, h / 2, w / 2, 1, c.at(p.dc5), 128, h / 2, w / 2, g[6]));
     CK(vsr_launch_up2_bwd(dt, c.at(p.du4), c.at(p.ds4), c.at(p.dc4), c.at(p.a4), SLOPE, n, h / 4, w / 4, 256, c.st));
     // ---- conv_4 (512 -> 256 at H/4) ----
-    CK(c.wide(c.at(p.dc4), 256, h / 4, w / 4, 1, h / 4, w / 4, p.wd[4], c.at(p.du3), 512, 1, ACT_NONE));
+    CK(c.wide(c.at(p.dc4), 256, h / 4, w / 4, 1, h / 4, w / 4, p.wd[4], p.dw2[4], c.at(p.du3), 512, 1, ACT_NONE));
     if (g[5]) CK(c.wgrad_layer(c.at(p.u3), 512, h / 4, w / 4, 1, c.at(p.dc4), 256, h / 4, w / 4, g[5]));
     CK(vsr_launch_up2_bwd(dt, c.at(p.du3), nullptr, c.at(p.dc3), c.at(p.f3), SLOPE, n, h / 8, w / 8, 512, c.st));
     // ---- conv_3 (256 -> 512, 4x4 stride 2): d c2 = (dgrad + d s4) * LeakyReLU'(f2) ----
-    CK(c.wide(c.at(p.dc3), 512, h / 8, w / 8, 1, h / 8, w / 8, p.wd[3], c.at(p.dc2), 256, 2, ACT_NONE, nullptr, c.at(p.ds4), nullptr, c.at(p.f2)));
+    CK(c.wide(c.at(p.dc3), 512, h / 8, w / 8, 1, h / 8, w / 8, p.wd[3], p.dw2[3], c.at(p.dc2), 256, 2, ACT_NONE, nullptr, c.at(p.ds4), nullptr, c.at(p.f2)));
     if (g[4]) CK(c.wgrad_layer(c.at(p.f2), 256, h / 4, w / 4, 4, c.at(p.dc3), 512, h / 8, w / 8, g[4]));
     // ---- conv_2 (128 -> 256) ----
-    CK(c.wide(c.at(p.dc2), 256, h / 4, w / 4, 1, h / 4, w / 4, p.wd[2], c.at(p.dc1), 128, 2, ACT_NONE, nullptr, c.at(p.ds5), nullptr, c.at(p.f1)));
+    CK(c.wide(c.at(p.dc2), 256, h / 4, w / 4, 1, h / 4, w / 4, p.wd[2], p.dw2[2], c.at(p.dc1), 128, 2, ACT_NONE, nullptr, c.at(p.ds5), nullptr, c.at(p.f1)));
     if (g[3]) CK(c.wgrad_layer(c.at(p.f1), 128, h / 2, w / 2, 4, c.at(p.dc2), 256, h / 4, w / 4, g[3]));
     // ---- conv_1 (64 -> 128) ----
-    CK(c.wide(c.at(p.dc1), 128, h / 2, w / 2, 1, h / 2, w / 2, p.wd[1], c.at(p.dc0), 64, 2, ACT_NONE, nullptr, c.at(p.G6), nullptr, c.at(p.f0)));
+    CK(c.wide(c.at(p.dc1), 128, h / 2, w / 2, 1, h / 2, w / 2, p.wd[1], p.dw2[1], c.at(p.dc0), 64, 2, ACT_NONE, nullptr, c.at(p.G6), nullptr, c.at(p.f0)));
     if (g[2]) CK(c.wgrad_layer(c.at(p.f0), 64, h, w, 4, c.at(p.dc1), 128, h / 2, w / 2, g[2]));
     // ---- conv_0 (3 -> 64 on the planar image) ----
     if (g[0]) {

@@ -53,9 +53,12 @@ struct VsrWideConv {
     void* y; int yC, Hy, Wy, out_step, ncob;
     int act; float slope;
     void* y_act; const void* res; void* y_pre; const void* aux;
+    const void* wpack2;            // bf16, yC a multiple of 128: weights in conv_wide2's image (vsr_launch_pack_wide2); wpack unused
 };
 int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st);
 long long vsr_wide_pack_elems(int cout, int cin, int mode);
+long long vsr_wide2_pack_elems(int cout, int cin, int mode);
+int vsr_launch_pack_wide2(const float* w, void* dst, int cout, int cin, int mode, hipStream_t st);
 int vsr_launch_pack_wide(int dtype, const float* w, void* dst, int cout, int cin, int mode, hipStream_t st);
 int vsr_launch_wgrad_reduce_s2(const float* slab, int nwg, int slab_stride, float* gw, int cin_total, int co0, int ci0, int view, hipStream_t st);
 int vsr_launch_up2_fwd(int dtype, const void* a, const void* b, void* out, int N, int H, int W, int C, hipStream_t st);
