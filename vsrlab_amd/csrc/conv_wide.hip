@@ -601,18 +601,17 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float* f)
 // out (N, 2H, 2W, C) = up2(a [+ b]);  a, b: (N, H, W, C)
 template <typename T>
 __global__ void up2_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int N, int H, int W, int C) {
-    // thread -> (pixel of a 32-pixel segment, 8-channel chunk, segment, row, image): consecutive lanes touch consecutive 16-byte
-    // chunks of the blocked layout, so every store is a full 512-byte run
+    // grid = (chunks of a row / 256, output row, image); thread -> (pixel of a 32-pixel segment, 8-channel chunk, segment): consecutive
+    // lanes touch consecutive 16-byte chunks of the blocked layout (every store is a full 512-byte run); 32-bit index arithmetic only
     const int CP = C >> 3, H2 = 2 * H, W2 = 2 * W, WS2 = pm_ws(W2);
-    const long long total = (long long)N * H2 * WS2 * CP * 32;
     const long long in_img = pm_image_elems(H, W, C), out_img = pm_image_elems(H2, W2, C);
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int px = (int)(idx & 31);
-        long long r = idx >> 5;
-        const int c = (int)(r % CP); r /= CP;
-        const int X = (int)(r % WS2) * 32 + px; r /= WS2;
-        const int Y = (int)(r % H2), n = (int)(r / H2);
-        if (X >= W2) continue;
+    const int Y = blockIdx.y, n = blockIdx.z;
+    {
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= WS2 * CP * 32) return;
+        const int px = idx & 31, r = idx >> 5;
+        const int c = r % CP, X = (r / CP) * 32 + px;
+        if (X >= W2) return;
         int y0, y1, x0, x1; float ly, lx;
         up2_src(Y, H, y0, y1, ly); up2_src(X, W, x0, x1, lx);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -638,15 +637,14 @@ template <typename T>
 __global__ void up2_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, T* __restrict__ dmask, const T* __restrict__ m, float slope,
                                int N, int H, int W, int C) {
     const int CP = C >> 3, H2 = 2 * H, W2 = 2 * W, WS = pm_ws(W);
-    const long long total = (long long)N * H * WS * CP * 32;
     const long long in_img = pm_image_elems(H, W, C), out_img = pm_image_elems(H2, W2, C);
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int px = (int)(idx & 31);
-        long long r = idx >> 5;
-        const int c = (int)(r % CP); r /= CP;
-        const int x = (int)(r % WS) * 32 + px; r /= WS;
-        const int y = (int)(r % H), n = (int)(r / H);
-        if (x >= W) continue;
+    const int y = blockIdx.y, n = blockIdx.z;
+    {
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= WS * CP * 32) return;
+        const int px = idx & 31, r = idx >> 5;
+        const int c = r % CP, x = (r / CP) * 32 + px;
+        if (x >= W) return;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int Y = 2 * y - 1; Y <= 2 * y + 2; ++Y) {
             if (Y < 0 || Y >= H2) continue;
@@ -907,9 +905,10 @@ int vsr_launch_wgrad_reduce_s2(const float* slab, int nwg, int slab_stride, floa
 
 int vsr_launch_up2_fwd(int dtype, const void* a, const void* b, void* out, int N, int H, int W, int C, hipStream_t st) {
     if (!a || !out || N < 1 || H < 1 || W < 1 || (C & 7)) return VSR_ERR_BADARG;
-    const long long total = (long long)N * 2 * H * pm_ws(2 * W) * 32 * (C / 8);
-    if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_fwd_kernel<bf16_t>, dim3(wgrid(total)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, N, H, W, C);
-    else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_fwd_kernel<float>, dim3(wgrid(total)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, H, W, C);
+    if (N > 65535 || 2 * H > 65535) return VSR_ERR_UNSUPPORTED;
+    const dim3 grid(cdiv(pm_ws(2 * W) * 32 * (C / 8), 256), 2 * H, N);
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, N, H, W, C);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, H, W, C);
     else return VSR_ERR_BADARG;
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
@@ -917,9 +916,10 @@ int vsr_launch_up2_fwd(int dtype, const void* a, const void* b, void* out, int N
 
 int vsr_launch_up2_bwd(int dtype, const void* dout, void* din, void* dmask, const void* m, float slope, int N, int H, int W, int C, hipStream_t st) {
     if (!dout || (!din && !dmask) || (dmask && !m) || N < 1 || H < 1 || W < 1 || (C & 7)) return VSR_ERR_BADARG;
-    const long long total = (long long)N * H * pm_ws(W) * 32 * (C / 8);
-    if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_bwd_kernel<bf16_t>, dim3(wgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)din, (bf16_t*)dmask, (const bf16_t*)m, slope, N, H, W, C);
-    else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(wgrid(total)), dim3(256), 0, st, (const float*)dout, (float*)din, (float*)dmask, (const float*)m, slope, N, H, W, C);
+    if (N > 65535 || H > 65535) return VSR_ERR_UNSUPPORTED;
+    const dim3 grid(cdiv(pm_ws(W) * 32 * (C / 8), 256), H, N);
+    if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)din, (bf16_t*)dmask, (const bf16_t*)m, slope, N, H, W, C);
+    else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (float*)din, (float*)dmask, (const float*)m, slope, N, H, W, C);
     else return VSR_ERR_BADARG;
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
