@@ -310,7 +310,7 @@ struct Wide2Args {
     unsigned tapmask[4];
     const float* bias;
     void* y; long long y_nstride; int yCP, Hy, Wy, out_step, ncp;
-    int act; float slope; const void* res; const void* aux;
+    int act; float slope; const void* res; const void* aux; void* y_act;
 };
 
 __device__ uint4 g_w2_zero_chunk[1];
@@ -321,6 +321,11 @@ __device__ uint4 g_w2_zero_chunk[1];
 
 struct __attribute__((aligned(8))) w2bf4 { bf16_t v[4]; };
 
+//   * KS = true (64-channel output blocks: conv_6 forward, conv_1's data gradient): the two wave halves split K instead of the
+//     output channels -- half kh takes the channels 32 kh .. 32 kh + 31 of every slice, a slab is [2 taps][64 rows][64 k] (same
+//     16 KiB, same 32 MFMAs per wave and step), and the halves' accumulators are summed through the idle tile buffer before the
+//     epilogue, which waves kh = 0 run.
+template <bool KS>
 __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -384,8 +389,9 @@ __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a)
     // A (weights) lane base: row ch*64 + 16 mb + l15 of the slab, chunk (4 kk + q) ^ ((row >> 1) & 7); B (pixels) lane base as persist
     unsigned a_lane[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) a_lane[kk] = (unsigned)(((ch * 64 + l15) * 8 + ((4 * kk + q) ^ ((l15 >> 1) & 7))) * 16);
-    const unsigned b_lane = (unsigned)(3 * W2_WSLAB + pg * 2 * (TWH * 128) + q * (TWH * 16) + pxl * 16);
+    for (int kk = 0; kk < 2; ++kk) a_lane[kk] = KS ? (unsigned)((l15 * 8 + ((4 * ch + q) ^ ((l15 >> 1) & 7))) * 16)
+                                                   : (unsigned)(((ch * 64 + l15) * 8 + ((4 * kk + q) ^ ((l15 >> 1) & 7))) * 16);
+    const unsigned b_lane = (unsigned)(3 * W2_WSLAB + pg * 2 * (TWH * 128) + q * (TWH * 16) + pxl * 16 + (KS ? ch * (4 * TWH * 16) : 0));
 
     // ---- prologue: first tile's first source, W(0), W(1) ----
     int tile = blockIdx.x;
@@ -407,15 +413,45 @@ __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cp * 128 + ch * 64 + mb * 16 + 4 * q);
+            if (a.bias && !(KS && ch)) bv = *reinterpret_cast<const float4*>(a.bias + (KS ? cp * 64 : cp * 128 + ch * 64) + mb * 16 + 4 * q);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) { acc[mb][nb][0] = bv.x; acc[mb][nb][1] = bv.y; acc[mb][nb][2] = bv.z; acc[mb][nb][3] = bv.w; }
+        }
+        // epilogue operands (residual, activation-gradient mask source): requested now, used after the K loop (loads return in
+        // order, so they are older than every DMA the counted waits below leave in flight)
+        w2bf4 rr[4][4], mm[4][4];
+        long long pixo[4];
+        bool ok[4];
+        {
+            const int n = tile / per_img, r = tile - n * per_img;
+            const int ty0 = (r / ntx) * TH, tx0 = (r % ntx) * TW;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int vy = ty0 + 2 * pg + (nb >> 1), vx = tx0 + (nb & 1) * 16 + pxl;
+                ok[nb] = vy < a.H && vx < a.W && (!KS || ch == 0);
+                const int oyy = vy * a.out_step + (a.out_step == 2 ? (oph >> 1) : 0);
+                const int oxx = vx * a.out_step + (a.out_step == 2 ? (oph & 1) : 0);
+                pixo[nb] = (long long)n * a.y_nstride + (((long long)oyy * WSy + (oxx >> 5)) * a.yCP + (KS ? cp * 8 : cp * 16 + ch * 8)) * 256 + (oxx & 31) * 8
+                           + (q >> 1) * 256 + 4 * (q & 1);
+                if (ok[nb]) {
+                    if (a.res) {
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) rr[mb][nb] = *reinterpret_cast<const w2bf4*>(reinterpret_cast<const bf16_t*>(a.res) + pixo[nb] + mb * 512);
+                    }
+                    if (a.aux) {
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) mm[mb][nb] = *reinterpret_cast<const w2bf4*>(reinterpret_cast<const bf16_t*>(a.aux) + pixo[nb] + mb * 512);
+                    }
+                }
+            }
         }
         for (int s = 0; s < a.nsrc; ++s) {
             const unsigned mask = a.tapmask[a.in_step == 2 ? s / a.nsl : oph];
             const bool last_src = s + 1 == a.nsrc;
             const bool has_next = !last_src || t + 1 < my_tiles;
-            bool first = true;
+            bool first = true, step_w = false, step_t = false;
+            int half = 0;
+            unsigned ab[2] = {0u, 0u};
             const unsigned bb = b_lane + (unsigned)(tb * W2_TILE);
             bf16x8_t fa[2][4], fb[2][4];
 #define W2_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
@@ -424,44 +460,63 @@ __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a)
 #define W2_LOADB(ky_, kx_, kk_, slot) { W2_LOADB1(ky_, kx_, kk_, slot, 0) W2_LOADB1(ky_, kx_, kk_, slot, 1) W2_LOADB1(ky_, kx_, kk_, slot, 2) W2_LOADB1(ky_, kx_, kk_, slot, 3) }
 #define W2_MFMA(slot, mb, nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][mb], fb[slot][nb], acc[mb][nb], 0, 0, 0);
 #define W2_MFMA_ROW(slot, mb) W2_MFMA(slot, mb, 0) W2_MFMA(slot, mb, 1) W2_MFMA(slot, mb, 2) W2_MFMA(slot, mb, 3)
-#define W2_STEP(tap_)                                                                                                   \
-            if (mask & (1u << (tap_))) {                                                                                \
-                constexpr int ky_ = (tap_) / 3, kx_ = (tap_) % 3;                                                       \
+#define W2_STEP_BEGIN                                                                                                   \
                 const bool w_issued = K + 2 < Ktot;                                                                     \
                 if (w_issued) issue_w(k2, wb2);                                                                         \
                 const bool t_issued = first && has_next;                                                                \
                 if (t_issued) { if (last_src) issue_tile(tile + gridDim.x, 0, tb ^ 1); else issue_tile(tile, s + 1, tb ^ 1); } \
-                unsigned ab[2];                                                                                         \
                 ab[0] = a_lane[0] + (unsigned)(wbi * W2_WSLAB); ab[1] = a_lane[1] + (unsigned)(wbi * W2_WSLAB);         \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_LOADA(0, 0) W2_LOADB(ky_, kx_, 0, 0)                                                                 \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_MFMA_ROW(0, 0)                                                                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_LOADA(1, 1)                                                                                          \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_MFMA_ROW(0, 1)                                                                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_LOADB(ky_, kx_, 1, 1)                                                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_MFMA_ROW(0, 2) W2_MFMA_ROW(0, 3)                                                                     \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                W2_MFMA_ROW(1, 0) W2_MFMA_ROW(1, 1) W2_MFMA_ROW(1, 2) W2_MFMA_ROW(1, 3)                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                step_w = w_issued; step_t = t_issued;
+#define W2_STEP_END                                                                                                     \
                 if (post_epi == 2) { post_epi = 1; }                                                                    \
-                else if (post_epi == 1 || !w_issued) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); post_epi = 0; } \
-                else if (t_issued || prev_tile_dma) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }                \
+                else if (post_epi == 1 || !step_w) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); post_epi = 0; }   \
+                else if (step_t || prev_tile_dma) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }                  \
                 else { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                                               \
                 __builtin_amdgcn_s_barrier();                                                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                                      \
-                prev_tile_dma = t_issued;                                                                               \
+                prev_tile_dma = step_t;                                                                                 \
                 first = false;                                                                                          \
-                ++K; wbi = wbi == 2 ? 0 : wbi + 1; wb2 = wb2 == 2 ? 0 : wb2 + 1; k2 = k2 + 1 == a.nsteps ? 0 : k2 + 1;  \
+                ++K; wbi = wbi == 2 ? 0 : wbi + 1; wb2 = wb2 == 2 ? 0 : wb2 + 1; k2 = k2 + 1 == a.nsteps ? 0 : k2 + 1;
+#define W2_STEP(tap_)                                                                                                   \
+            if (mask & (1u << (tap_))) {                                                                                \
+                constexpr int ky_ = (tap_) / 3, kx_ = (tap_) % 3;                                                       \
+                if (!KS) {                                                                                              \
+                    W2_STEP_BEGIN                                                                                       \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_LOADA(0, 0) W2_LOADB(ky_, kx_, 0, 0)                                                             \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_MFMA_ROW(0, 0)                                                                                   \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_LOADA(1, 1)                                                                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_MFMA_ROW(0, 1)                                                                                   \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_LOADB(ky_, kx_, 1, 1)                                                                            \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_MFMA_ROW(0, 2) W2_MFMA_ROW(0, 3)                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_MFMA_ROW(1, 0) W2_MFMA_ROW(1, 1) W2_MFMA_ROW(1, 2) W2_MFMA_ROW(1, 3)                             \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_STEP_END                                                                                         \
+                } else {                                                                                                \
+                    if (half == 0) { W2_STEP_BEGIN }                                                                    \
+                    else { ab[0] += 8192u; }             /* second tap of the slab: rows 64 .. 127 */                   \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_LOADA(0, 0) W2_LOADB(ky_, kx_, 0, 0)                                                             \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    W2_MFMA_ROW(0, 0) W2_MFMA_ROW(0, 1) W2_MFMA_ROW(0, 2) W2_MFMA_ROW(0, 3)                             \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    if (half == 1 || (mask >> ((tap_) + 1)) == 0u) { W2_STEP_END half = 0; }                            \
+                    else half = 1;                                                                                      \
+                }                                                                                                       \
             }
             W2_STEP(0) W2_STEP(1) W2_STEP(2) W2_STEP(3) W2_STEP(4) W2_STEP(5) W2_STEP(6) W2_STEP(7) W2_STEP(8)
+#undef W2_STEP_BEGIN
+#undef W2_STEP_END
 #undef W2_STEP
 #undef W2_MFMA_ROW
 #undef W2_MFMA
@@ -475,19 +530,38 @@ __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         post_epi = 2;
         prev_tile_dma = false;
+        if (KS) {
+            // sum the K halves through the tile buffer the last source used (tb was flipped: the OTHER buffer holds the next tile)
+            float* ex = reinterpret_cast<float*>(lds_t + (tb ^ 1) * W2_TILE) + pg * 32 * 64 + lane;
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                if (ch == 1) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ex[((m * 4 + nb) * 4 + j) * 64] = acc[2 * hp + m][nb][j];
+                }
+                __syncthreads();
+                if (ch == 0) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[2 * hp + m][nb][j] += ex[((m * 4 + nb) * 4 + j) * 64];
+                }
+                __syncthreads();
+            }
+        }
         {
-            const int n = tile / per_img, r = tile - n * per_img;
-            const int ty0 = (r / ntx) * TH, tx0 = (r % ntx) * TW;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const int vy = ty0 + 2 * pg + (nb >> 1), vx = tx0 + (nb & 1) * 16 + pxl;
-                if (vy < a.H && vx < a.W) {
-                    const int oyy = vy * a.out_step + (a.out_step == 2 ? (oph >> 1) : 0);
-                    const int oxx = vx * a.out_step + (a.out_step == 2 ? (oph & 1) : 0);
-                    const long long pix = (long long)n * a.y_nstride + (((long long)oyy * WSy + (oxx >> 5)) * a.yCP + cp * 16 + ch * 8) * 256 + (oxx & 31) * 8;
+                if (ok[nb]) {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) {
-                        const long long o = pix + (2 * mb + (q >> 1)) * 256 + 4 * (q & 1);
+                        const long long o = pixo[nb] + mb * 512;
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = acc[mb][nb][j];
@@ -498,15 +572,19 @@ __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
                         }
-                        if (a.res) {
-                            const w2bf4 rr = *reinterpret_cast<const w2bf4*>(reinterpret_cast<const bf16_t*>(a.res) + o);
+                        if (a.y_act) {
+                            w2bf4 t;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += (float)rr.v[j];
+                            for (int j = 0; j < 4; ++j) t.v[j] = (bf16_t)v[j];
+                            *reinterpret_cast<w2bf4*>(reinterpret_cast<bf16_t*>(a.y_act) + o) = t;
+                        }
+                        if (a.res) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)rr[mb][nb].v[j];
                         }
                         if (a.aux) {
-                            const w2bf4 mm = *reinterpret_cast<const w2bf4*>(reinterpret_cast<const bf16_t*>(a.aux) + o);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mm.v[j] > 0.f ? 1.f : a.slope);
+                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mm[mb][nb].v[j] > 0.f ? 1.f : a.slope);
                         }
                         w2bf4 out;
 #pragma unroll
@@ -523,33 +601,36 @@ __global__ __launch_bounds__(W2_NT, 1) void conv_wide2_kernel(const Wide2Args a)
 // steps in execution order: source (view-major, then slice), then the ACTIVE taps of that source in increasing tap index.
 // Modes as pack_wide_kernel.
 template <typename T>
-__global__ void pack_wide2_kernel(const float* __restrict__ w, T* __restrict__ dst, int cout, int cin, int mode, long long total) {
+__global__ void pack_wide2_kernel(const float* __restrict__ w, T* __restrict__ dst, int cout, int cin, int mode, int ks, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int e = (int)(idx & 7), cs = (int)((idx >> 3) & 7), r = (int)((idx >> 6) & 127);
     long long rest = idx >> 13;
     const bool s2 = mode == 1 || mode == 3;
-    const int tps = s2 ? 4 : 9;
+    const int tps = s2 ? 4 : 9, spt = ks ? (tps + 1) / 2 : tps;                 // taps / steps per source
     const int nsl = (mode == 0 || mode == 1 ? cin : cout) / 64, nviews = mode == 1 ? 4 : 1;
-    const int rows = (mode == 0 || mode == 1) ? cout : cin, ncp = rows / 128;
-    const int nsteps = nsl * nviews * tps;
+    const int rows = (mode == 0 || mode == 1) ? cout : cin, ncp = rows / (ks ? 64 : 128);
+    const int nsteps = nsl * nviews * spt;
     const int k = (int)(rest % nsteps), col = (int)(rest / nsteps);
     const int cp = col % ncp, oph = col / ncp;
-    const int src = k / tps, j = k - src * tps;
+    const int src = k / spt, st = k - src * spt;
+    const int j = ks ? 2 * st + (r >> 6) : st;                                   // KS: slab = [2 taps][64 rows]
     const int slice = src % nsl, view = src / nsl;
     const int ci = ((cs ^ ((r >> 1) & 7)) << 3) + e;
-    const int row = cp * 128 + r, colc = slice * 64 + ci;
-    float v;
-    if (mode == 0) {
-        v = w[((long long)row * cin + colc) * 9 + j];
-    } else if (mode == 2) {
-        v = w[((long long)colc * cin + row) * 9 + (8 - j)];
-    } else if (mode == 1) {
-        const int dy = ((view >> 1) ? -1 : 0) + (j >> 1), dx = ((view & 1) ? -1 : 0) + (j & 1);
-        v = w[((long long)row * cin + colc) * 16 + s2_fwd_k(view >> 1, dy) * 4 + s2_fwd_k(view & 1, dx)];
-    } else {
-        const int dy = ((oph >> 1) ? 0 : -1) + (j >> 1), dx = ((oph & 1) ? 0 : -1) + (j & 1);
-        v = w[((long long)colc * cin + row) * 16 + s2_bwd_k(oph >> 1, dy) * 4 + s2_bwd_k(oph & 1, dx)];
+    const int row = ks ? cp * 64 + (r & 63) : cp * 128 + r, colc = slice * 64 + ci;
+    float v = 0.f;
+    if (j < tps) {
+        if (mode == 0) {
+            v = w[((long long)row * cin + colc) * 9 + j];
+        } else if (mode == 2) {
+            v = w[((long long)colc * cin + row) * 9 + (8 - j)];
+        } else if (mode == 1) {
+            const int dy = ((view >> 1) ? -1 : 0) + (j >> 1), dx = ((view & 1) ? -1 : 0) + (j & 1);
+            v = w[((long long)row * cin + colc) * 16 + s2_fwd_k(view >> 1, dy) * 4 + s2_fwd_k(view & 1, dx)];
+        } else {
+            const int dy = ((oph >> 1) ? 0 : -1) + (j >> 1), dx = ((oph & 1) ? 0 : -1) + (j & 1);
+            v = w[((long long)colc * cin + row) * 16 + s2_bwd_k(oph >> 1, dy) * 4 + s2_bwd_k(oph & 1, dx)];
+        }
     }
     dst[idx] = (T)v;
 }
@@ -825,24 +906,31 @@ int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st) {
     }
     a.act = c.act; a.slope = c.slope; a.y_act = c.y_act; a.res = c.res; a.y_pre = c.y_pre; a.aux = c.aux;
     const int nph = c.out_step == 2 ? 4 : 1;
-    if (c.wpack2) {                                  // bf16, >= 128 output channels: the DMA-fed persistent kernel
-        if (dtype != VSR_BF16 || (c.ncob & 1) || c.y_act || c.y_pre) return VSR_ERR_BADARG;
+    if (c.wpack2) {                                  // bf16: the DMA-fed persistent kernel (64-channel output blocks: its K-split form)
+        if (dtype != VSR_BF16 || c.y_pre) return VSR_ERR_BADARG;
+        const bool ks = (c.ncob & 1) != 0;
         Wide2Args b = {};
         b.x = c.x; b.x_nstride = a.x_nstride; b.xCP = c.xC >> 3; b.Hx = c.Hx; b.Wx = c.Wx; b.in_step = c.in_step; b.nsl = c.nsl;
         b.nsrc = c.nsl * (c.in_step == 2 ? 4 : 1);
         b.N = c.N; b.H = c.H; b.W = c.W; b.wpack = c.wpack2;
-        b.nsteps = b.nsrc * ((c.in_step == 2 || c.out_step == 2) ? 4 : 9);
+        const int tps = (c.in_step == 2 || c.out_step == 2) ? 4 : 9;
+        b.nsteps = b.nsrc * (ks ? (tps + 1) / 2 : tps);
         for (int i = 0; i < 4; ++i) b.tapmask[i] = a.tapmask[i];
         b.bias = c.bias; b.y = c.y; b.y_nstride = a.y_nstride; b.yCP = c.yC >> 3; b.Hy = c.Hy; b.Wy = c.Wy; b.out_step = c.out_step;
-        b.ncp = c.ncob / 2; b.act = c.act; b.slope = c.slope; b.res = c.res; b.aux = c.aux;
+        b.ncp = ks ? c.ncob : c.ncob / 2; b.act = c.act; b.slope = c.slope; b.res = c.res; b.aux = c.aux; b.y_act = c.y_act;
         const int cols = b.ncp * nph;
         const int tiles = c.N * cdiv(c.H, TH) * cdiv(c.W, TW);
         int nwx = vsr_num_cus() / cols;
         if (nwx < 1) nwx = 1;
         if (nwx > tiles) nwx = tiles;
-        static VsrDevOnce once2;
-        { const int rc = vsr_set_max_dynamic_lds(once2, reinterpret_cast<const void*>(conv_wide2_kernel), W2_LDS); if (rc != VSR_OK) return rc; }
-        hipLaunchKernelGGL(conv_wide2_kernel, dim3(nwx, cols), dim3(W2_NT), W2_LDS, st, b);
+        static VsrDevOnce once2, once2k;
+        if (ks) {
+            { const int rc = vsr_set_max_dynamic_lds(once2k, reinterpret_cast<const void*>(conv_wide2_kernel<true>), W2_LDS); if (rc != VSR_OK) return rc; }
+            hipLaunchKernelGGL(conv_wide2_kernel<true>, dim3(nwx, cols), dim3(W2_NT), W2_LDS, st, b);
+        } else {
+            { const int rc = vsr_set_max_dynamic_lds(once2, reinterpret_cast<const void*>(conv_wide2_kernel<false>), W2_LDS); if (rc != VSR_OK) return rc; }
+            hipLaunchKernelGGL(conv_wide2_kernel<false>, dim3(nwx, cols), dim3(W2_NT), W2_LDS, st, b);
+        }
         HIP_CHECK_RET(hipGetLastError());
         return VSR_OK;
     }
@@ -881,18 +969,22 @@ int vsr_launch_pack_wide(int dtype, const float* w, void* dst, int cout, int cin
     return VSR_OK;
 }
 
+// rows = output channels of the launch (mode 0/1: cout, mode 2/3: cin); a multiple of 128 -> 128-row slabs, else the K-split image
 long long vsr_wide2_pack_elems(int cout, int cin, int mode) {
     const bool s2 = mode == 1 || mode == 3;
     const int nsl = (mode == 0 || mode == 1 ? cin : cout) / 64, rows = (mode == 0 || mode == 1) ? cout : cin;
-    const long long cols = (long long)(rows / 128) * (mode == 3 ? 4 : 1);
-    return cols * nsl * (mode == 1 ? 4 : 1) * (s2 ? 4 : 9) * 8192;
+    const bool ks = (rows & 127) != 0;
+    const int tps = s2 ? 4 : 9;
+    const long long cols = (long long)(rows / (ks ? 64 : 128)) * (mode == 3 ? 4 : 1);
+    return cols * nsl * (mode == 1 ? 4 : 1) * (ks ? (tps + 1) / 2 : tps) * 8192;
 }
 
 int vsr_launch_pack_wide2(const float* w, void* dst, int cout, int cin, int mode, hipStream_t st) {
     const int rows = (mode == 0 || mode == 1) ? cout : cin;
-    if (!w || !dst || (cout & 63) || (cin & 63) || (rows & 127) || mode < 0 || mode > 3) return VSR_ERR_BADARG;
+    if (!w || !dst || (cout & 63) || (cin & 63) || mode < 0 || mode > 3) return VSR_ERR_BADARG;
     const long long total = vsr_wide2_pack_elems(cout, cin, mode);
-    hipLaunchKernelGGL(pack_wide2_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (bf16_t*)dst, cout, cin, mode, total);
+    hipLaunchKernelGGL(pack_wide2_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (bf16_t*)dst, cout, cin, mode,
+                       (rows & 127) ? 1 : 0, total);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

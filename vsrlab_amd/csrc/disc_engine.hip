@@ -60,9 +60,8 @@ struct DPlan {
         const int co[7] = {0, 128, 256, 512, 256, 128, 64}, ci[7] = {0, 64, 128, 256, 512, 256, 128};
         for (int k = 1; k <= 6; ++k) {
             const bool s2 = k <= 3;
-            // bf16 layers with >= 128 output channels run on conv_wide2 (its own weight image): forward rows = cout, dgrad rows = cin
-            fw2[k] = dtype == VSR_BF16 && (co[k] & 127) == 0;
-            dw2[k] = dtype == VSR_BF16 && (ci[k] & 127) == 0;
+            // bf16 runs on conv_wide2 (its own weight image; 64-channel outputs: the K-split form)
+            fw2[k] = dw2[k] = dtype == VSR_BF16;
             wf[k] = b.take((size_t)(fw2[k] ? vsr_wide2_pack_elems(co[k], ci[k], s2 ? 1 : 0) : vsr_wide_pack_elems(co[k], ci[k], s2 ? 1 : 0)) * es);
             wd[k] = b.take((size_t)(dw2[k] ? vsr_wide2_pack_elems(co[k], ci[k], s2 ? 3 : 2) : vsr_wide_pack_elems(co[k], ci[k], s2 ? 3 : 2)) * es);
         }
