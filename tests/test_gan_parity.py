@@ -194,7 +194,10 @@ def test_config3_full_size_gan_iteration():
     losses and gradients, parameters move, a timing line.  (Values are pinned at small sizes above; this is the at-size run:
     ~230 GB of arenas.)"""
     dev = _gpu()
+    import gc
     import time
+    gc.collect()                      # earlier tests' autograd graphs (reference cycles) may still hold their arenas: this test needs 241 GiB
+    torch.cuda.empty_cache()
     from vsrlab_amd.core.losses import AdversarialLoss, CharbonnierLoss
     from vsrlab_amd.optim import FusedAdam
     from vsrlab_amd.train_gan import discriminator_step, dummy_loss, generator_step

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2);            // 0: MFMA consumer, 1: LDS-DMA producer
-    const int w4 = wave & 3;
+    const int w4 = __builtin_amdgcn_readfirstlane(wave & 3);
     const int tiles_per_img = a.ntiles_x * a.ntiles_y;
     const int per_seg = a.N * tiles_per_img;
     const int total = a.nseg * per_seg;
