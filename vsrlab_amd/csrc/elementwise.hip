@@ -2,7 +2,7 @@
 // the SPyNet pyramid plumbing (resize, normalise, average-pool, per-level warp+concat, flow
 // upsample), weight packing and small glue.  All are pure streaming kernels: one pass, 16-byte
 // accesses on pixel-major tensors, planar fp32 accesses coalesced along x.
-#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -748,6 +748,30 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     dst[idx] = (T)v;
 }
 
+struct PackArgs { int n; VsrPackDesc d[VSR_PACK_BATCH]; };
+static_assert(sizeof(PackArgs) <= 4096, "kernel arguments");
+
+// Many pack_weights_kernel launches in one: block -> tensor by binary search over the descriptors' first-block table.
+__global__ void pack_multi_kernel(const PackArgs a) {
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.d[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const VsrPackDesc& d = a.d[lo];
+    const int idx = ((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+    if (idx >= d.total) return;
+    const int KK = d.KK, RP = d.RP, CPd = d.CPd;
+    const int c = idx % CPd, r = (idx / CPd) % RP, tap = idx / (CPd * RP);
+    float v = 0.f;
+    if (r < d.r_real && c < d.c_real) {
+        if (d.mode == 0) v = d.w[((long long)(r * d.o_mul + d.o_add) * d.I_total + d.i_off + c) * KK + tap];
+        else v = d.w[((long long)(c * d.o_mul + d.o_add) * d.I_total + d.i_off + r) * KK + (KK - 1 - tap)];
+    }
+    if (d.dtype == VSR_BF16) reinterpret_cast<bf16_t*>(d.dst)[idx] = (bf16_t)v;
+    else reinterpret_cast<float*>(d.dst)[idx] = v;
+}
+
 __global__ void charbonnier_grad_kernel(const float* __restrict__ sr, const float* __restrict__ hr, float* __restrict__ dsr,
                                         float* __restrict__ loss_acc, long long n, float eps, float scale) {
     float local = 0.f;
@@ -909,6 +933,23 @@ int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP
     const int total = KK * RP * CPd;
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, st, w, (T*)dst, KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add, mode));
     HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+int vsr_launch_pack_multi(const VsrPackDesc* descs, int n, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += VSR_PACK_BATCH) {
+        PackArgs a;
+        a.n = n - i0 < VSR_PACK_BATCH ? n - i0 : VSR_PACK_BATCH;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            a.d[i] = descs[i0 + i];
+            if (a.d[i].total < 1 || !a.d[i].w || !a.d[i].dst || (a.d[i].dtype != VSR_BF16 && a.d[i].dtype != VSR_F32)) return VSR_ERR_BADARG;
+            a.d[i].blk0 = blocks;
+            blocks += cdiv(a.d[i].total, 256);
+        }
+        hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks), dim3(256), 0, st, a);
+        HIP_CHECK_RET(hipGetLastError());
+    }
     return VSR_OK;
 }
 

@@ -211,6 +211,7 @@ struct Ctx {
     hipStream_t st;
     int dtype;
     int lane;                   // 0: the caller's stream, 1: the helper stream (selects per-stream scratch)
+    mutable std::vector<VsrPackDesc>* batch = nullptr;      // while set, pack() collects descriptors for ONE multi-tensor launch
     void* at(size_t off) const { return ws + off; }
     const float* fat(size_t off) const { return reinterpret_cast<const float*>(ws + off); }
 
@@ -264,10 +265,21 @@ struct Ctx {
     }
     int pack(const float* w, size_t dst, int KK, int RP, int CPd, int r_real, int c_real, int I_total, int i_off, int o_mul,
              int o_add, int mode) const {
-        return vsr_launch_pack_weights(dtype, w, at(dst), KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add, mode, st);
+        return pack_any(dtype, w, at(dst), KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add, mode);
     }
     int pack_bias(const float* b, size_t dst, int nreal, int o_mul = 1, int o_add = 0) const {
-        return vsr_launch_pack_weights(VSR_F32, b, at(dst), 1, nreal, 1, nreal, 1, 1, 0, o_mul, o_add, 0, st);
+        return pack_any(VSR_F32, b, at(dst), 1, nreal, 1, nreal, 1, 1, 0, o_mul, o_add, 0);
+    }
+    int pack_any(int dt, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real, int I_total, int i_off, int o_mul,
+                 int o_add, int mode) const {
+        if (!batch) return vsr_launch_pack_weights(dt, w, dst, KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add, mode, st);
+        VsrPackDesc d = {};
+        d.w = w; d.dst = dst; d.total = KK * RP * CPd;
+        d.KK = (short)KK; d.RP = (short)RP; d.CPd = (short)CPd; d.r_real = (short)r_real; d.c_real = (short)c_real;
+        d.I_total = (short)I_total; d.i_off = (short)i_off; d.o_mul = (short)o_mul; d.o_add = (short)o_add;
+        d.mode = (unsigned char)mode; d.dtype = (unsigned char)dt;
+        batch->push_back(d);
+        return VSR_OK;
     }
 };
 
@@ -354,7 +366,19 @@ int spynet_run(const Ctx& c, const SpyPlan& sp, const float* frames, const float
     return vsr_launch_flow_out(c.fat(fprev), flows_out, P, hu, wu, sp.h, sp.w, c.st);
 }
 
+int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm);
+// every weight / bias pack of a forward (~465 tensors) in a handful of multi-tensor launches
 int pack_all(const Ctx& c, const Plan& p, const float* const* prm) {
+    std::vector<VsrPackDesc> descs;
+    descs.reserve(512);
+    c.batch = &descs;
+    const int rc = pack_all_collect(c, p, prm);
+    c.batch = nullptr;
+    if (rc != VSR_OK) return rc;
+    return vsr_launch_pack_multi(descs.data(), (int)descs.size(), c.st);
+}
+
+int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm) {
     const PIdx ix{p.rb};
     const int dt = c.dtype; (void)dt;
     for (int dir = 0; dir < 2; ++dir) {

@@ -40,6 +40,16 @@ int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride,
                            int* nslabs, hipStream_t st);
 int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float* w, const void* aux, void* dst, int N, int H, int W,
                            int mask_mode, hipStream_t st, const void* sign_bits = nullptr, float slope = 0.f);
+// One weight pack of vsr_launch_pack_weights as data: a forward packs ~465 tensors, batched into a handful of launches
+// (vsr_launch_pack_multi: descriptors travel in the kernel arguments, VSR_PACK_BATCH per launch).
+struct VsrPackDesc {
+    const float* w; void* dst;
+    int total, blk0;                                       // elements; first 256-thread block of this tensor within its launch
+    short KK, RP, CPd, r_real, c_real, I_total, i_off, o_mul, o_add;
+    unsigned char mode, dtype;
+};
+#define VSR_PACK_BATCH 80
+int vsr_launch_pack_multi(const VsrPackDesc* descs, int n, hipStream_t st);
 int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
                             int I_total, int i_off, int o_mul, int o_add, int mode, hipStream_t st);
 int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps,
