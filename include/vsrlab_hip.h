@@ -237,9 +237,11 @@ int vsr_disc_backward(const VsrDiscDesc* d, float* const* grads, int nparams, co
  * w_out = w_orig / sigma.  rows <= 512.                                                                            */
 int vsr_spectral_norm(const float* w_orig, float* u, float* v, float* w_out, float* sigma, int rows, int cols,
                       int training, void* stream);
-/* dw_orig += dw / sigma - (sum(dw * w_orig) / sigma^2) u v^T   (u, v are constants of the graph, as in torch)        */
+/* dw_orig += dw / sigma - (sum(dw * w_orig) / sigma^2) u v^T   (u, v are constants of the graph, as in torch).
+ * scratch: VSR_SN_SCRATCH_FLOATS floats of device memory (per-workgroup partial sums; fixed summation order).        */
+#define VSR_SN_SCRATCH_FLOATS 1024
 int vsr_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v, const float* sigma,
-                               float* dw_orig, int rows, int cols, void* stream);
+                               float* dw_orig, int rows, int cols, float* scratch, void* stream);
 
 /* AdversarialLoss's core (core/losses.py:66-74): loss[0] = mean BCE-with-logits(x, target); dx (optional) = its gradient */
 int vsr_bce_with_logits(const float* x, float target, float* dx, float* loss, long long numel, void* stream);

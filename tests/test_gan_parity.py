@@ -54,8 +54,9 @@ def test_spectral_norm_kernel_forward_backward():
                 assert rel_err(ud.cpu(), u1) < 1e-5 and rel_err(vd.cpu(), v1) < 1e-5
                 assert rel_err(out.cpu(), wn.detach()) < 1e-5 and abs(float(sg) - float(sigma)) < 1e-5 * float(sigma)
                 gd = torch.zeros_like(wd)
+                scr = torch.empty(1024, device=dev)
                 assert lib.vsr_spectral_norm_backward(VF._ptr(cot.float().to(dev)), VF._ptr(wd), VF._ptr(ud), VF._ptr(vd), VF._ptr(sg),
-                                                      VF._ptr(gd), co, ci * ks * ks, st) == 0
+                                                      VF._ptr(gd), co, ci * ks * ks, VF._ptr(scr), st) == 0
                 assert rel_err(gd.cpu(), w64.grad) < 1e-4
             else:
                 wn0, _, _, _ = D.spectral_normalize(w.double(), u.double(), v.double(), False)

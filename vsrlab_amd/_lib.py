@@ -71,7 +71,7 @@ _SIGNATURES = {
     "vsr_disc_forward": (c_int, [ctypes.POINTER(DiscDesc), _P, c_int, _P, _P, _P, c_size_t, c_int, _P]),
     "vsr_disc_backward": (c_int, [ctypes.POINTER(DiscDesc), _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "vsr_spectral_norm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "vsr_spectral_norm_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "vsr_spectral_norm_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "vsr_bce_with_logits": (c_int, [_P, c_float, _P, _P, c_longlong, _P]),
     "vsr_window_attention_fwd": (c_int, [ctypes.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
     "vsr_window_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

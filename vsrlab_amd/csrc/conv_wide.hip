@@ -679,38 +679,55 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float* f)
     reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
 }
 
-// out (N, 2H, 2W, C) = up2(a [+ b]);  a, b: (N, H, W, C)
+// out (N, 2H, 2W, C) = up2(a [+ b]);  a, b: (N, H, W, C).  One thread = one SOURCE pixel x 8 channels -> its 2 x 2 output pixels from the
+// clamped 3 x 3 source neighbourhood (x2 bilinear, align_corners=False, is separable with weights (1/4, 3/4) / (3/4, 1/4); at the image
+// border the clamped neighbour carries the missing weight, which is exactly torch's source-index clamp): 2.25 (4.5 with b) 16-byte loads
+// per output instead of 4 (8).  grid = (chunks of a source row / 256, source row, image); consecutive lanes = consecutive pixels of a
+// 32-pixel segment, so loads are 512-byte runs and the two stores of an output row cover two full output segments between them.
 template <typename T>
 __global__ void up2_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int N, int H, int W, int C) {
-    // grid = (chunks of a row / 256, output row, image); thread -> (pixel of a 32-pixel segment, 8-channel chunk, segment): consecutive
-    // lanes touch consecutive 16-byte chunks of the blocked layout (every store is a full 512-byte run); 32-bit index arithmetic only
-    const int CP = C >> 3, H2 = 2 * H, W2 = 2 * W, WS2 = pm_ws(W2);
-    const long long in_img = pm_image_elems(H, W, C), out_img = pm_image_elems(H2, W2, C);
-    const int Y = blockIdx.y, n = blockIdx.z;
-    {
-        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-        if (idx >= WS2 * CP * 32) return;
-        const int px = idx & 31, r = idx >> 5;
-        const int c = r % CP, X = (r / CP) * 32 + px;
-        if (X >= W2) return;
-        int y0, y1, x0, x1; float ly, lx;
-        up2_src(Y, H, y0, y1, ly); up2_src(X, W, x0, x1, lx);
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int CP = C >> 3, W2 = 2 * W, WS = pm_ws(W);
+    const long long in_img = pm_image_elems(H, W, C), out_img = pm_image_elems(2 * H, W2, C);
+    const int y = blockIdx.y, n = blockIdx.z;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= WS * CP * 32) return;
+    const int px = idx & 31, r = idx >> 5;
+    const int c = r % CP, x = (r / CP) * 32 + px;
+    if (x >= W) return;
+    const int ys[3] = {y > 0 ? y - 1 : 0, y, y < H - 1 ? y + 1 : H - 1};
+    const int xs[3] = {x > 0 ? x - 1 : 0, x, x < W - 1 ? x + 1 : W - 1};
+    float h0[3][8], h1[3][8];                                 // horizontally interpolated rows: output columns 2x, 2x + 1
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int yy = (t >> 1) ? y1 : y0, xx = (t & 1) ? x1 : x0;
-            const float wgt = ((t >> 1) ? ly : 1.f - ly) * ((t & 1) ? lx : 1.f - lx);
-            const long long o = (long long)n * in_img + pm_off(yy, xx, c, W, C);
-            float f[8];
-            ld8<T>(a + o, f);
-            if (b) { float g[8]; ld8<T>(b + o, g);
+    for (int i = 0; i < 3; ++i) {
+        float v[3][8];
 #pragma unroll
-                     for (int j = 0; j < 8; ++j) f[j] += g[j]; }
+        for (int j = 0; j < 3; ++j) {
+            const long long o = (long long)n * in_img + pm_off(ys[i], xs[j], c, W, C);
+            ld8<T>(a + o, v[j]);
+            if (b) {
+                float g[8];
+                ld8<T>(b + o, g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
+                for (int k = 0; k < 8; ++k) v[j][k] += g[k];
+            }
         }
-        st8<T>(out + (long long)n * out_img + pm_off(Y, X, c, W2, C), acc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            h0[i][k] = 0.25f * v[0][k] + 0.75f * v[1][k];
+            h1[i][k] = 0.75f * v[1][k] + 0.25f * v[2][k];
+        }
     }
+    float o00[8], o01[8], o10[8], o11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        o00[k] = 0.25f * h0[0][k] + 0.75f * h0[1][k]; o01[k] = 0.25f * h1[0][k] + 0.75f * h1[1][k];
+        o10[k] = 0.75f * h0[1][k] + 0.25f * h0[2][k]; o11[k] = 0.75f * h1[1][k] + 0.25f * h1[2][k];
+    }
+    T* ob = out + (long long)n * out_img;
+    st8<T>(ob + pm_off(2 * y, 2 * x, c, W2, C), o00);
+    st8<T>(ob + pm_off(2 * y, 2 * x + 1, c, W2, C), o01);
+    st8<T>(ob + pm_off(2 * y + 1, 2 * x, c, W2, C), o10);
+    st8<T>(ob + pm_off(2 * y + 1, 2 * x + 1, c, W2, C), o11);
 }
 
 // adjoint: din (N, H, W, C) = up2^T(dout (N, 2H, 2W, C)); optionally also din * (m > 0 ? 1 : slope) into dmask
@@ -845,24 +862,72 @@ __global__ __launch_bounds__(1024) void spectral_norm_kernel(const float* __rest
     }
 }
 
-// gradient through weight = W / sigma, sigma = u^T W v (u, v constants):
-//   dW = dWn / sigma - (sum(dWn * W) / sigma^2) * u v^T
-__global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(const float* __restrict__ dWn, const float* __restrict__ W, const float* __restrict__ u,
-                                                                 const float* __restrict__ v, const float* __restrict__ sigma_p,
-                                                                 float* __restrict__ dW, int R, int K) {
+// Training-mode power iteration in five small launches (the single-workgroup kernel above streams a <= 9.4 MB matrix three times through
+// one CU: ~480 us per layer, 23 ms per GAN iteration).  Same arithmetic, fixed summation orders (no atomics):
+//   sn_wtu: v <- W^T u (unnormalised), one thread per column, rows streamed coalesced
+//   sn_norm: x <- x / max(||x||, eps) in one workgroup; optionally sigma = sum(x_old^2) / ||x_old|| (= u . (W v) for the fresh u)
+//   sn_wv:  u <- W v (unnormalised), one wave per row
+//   sn_scale: Wn = W / sigma
+__global__ void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ v, int R, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < R; r += 4) {
+        s0 += W[(long long)r * K + k] * u[r];
+        s1 += W[(long long)(r + 1) * K + k] * u[r + 1];
+        s2 += W[(long long)(r + 2) * K + k] * u[r + 2];
+        s3 += W[(long long)(r + 3) * K + k] * u[r + 3];
+    }
+    for (; r < R; ++r) s0 += W[(long long)r * K + k] * u[r];
+    v[k] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(1024) void sn_norm_kernel(float* __restrict__ x, int n, float eps, float* __restrict__ sigma_out) {
     __shared__ float red[16];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const long long n = (long long)R * K;
     float part = 0.f;
-    for (long long i = tid; i < n; i += nt) part += dWn[i] * W[i];
-    const float dot = blk_sum(part, red);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) part += x[i] * x[i];
+    const float ss = blk_sum(part, red);
+    const float nrm = fmaxf(sqrtf(ss), eps);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = x[i] / nrm;
+    if (sigma_out && threadIdx.x == 0) sigma_out[0] = ss / nrm;          // sum_r (s_r / nrm) s_r
+}
+__global__ void sn_wv_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ u, int R, int K) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += W[(long long)r * K + k] * v[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) u[r] = s;
+}
+__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ sigma, float* __restrict__ Wn, long long n) {
+    const float sg = sigma[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) Wn[i] = W[i] / sg;
+}
+// backward in two launches: per-block partial sums of dWn * W (scratch), then the rank-1 corrected update
+__global__ void sn_bwd_dot_kernel(const float* __restrict__ dWn, const float* __restrict__ W, float* __restrict__ partial, long long n) {
+    __shared__ float red[16];
+    float part = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) part += dWn[i] * W[i];
+    const float s = blk_sum(part, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void sn_bwd_apply_kernel(const float* __restrict__ dWn, const float* __restrict__ u, const float* __restrict__ v,
+                                    const float* __restrict__ sigma_p, const float* __restrict__ partial, int nparts, float* __restrict__ dW,
+                                    int R, int K) {
+    float dot = 0.f;
+    for (int i = 0; i < nparts; ++i) dot += partial[i];                 // same order in every thread
     const float sigma = sigma_p[0];
     const float coef = dot / (sigma * sigma);
-    for (long long i = tid; i < n; i += nt) {
+    const long long n = (long long)R * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / K), k = (int)(i - (long long)r * K);
         dW[i] += dWn[i] / sigma - coef * u[r] * v[k];
     }
 }
+
+// gradient through weight = W / sigma, sigma = u^T W v (u, v constants):  dW = dWn / sigma - (sum(dWn * W) / sigma^2) * u v^T
+// (sn_bwd_dot_kernel + sn_bwd_apply_kernel above)
 
 // ---- BCE with logits against a constant target, mean reduction (core/losses.py:66-74), value + gradient ----
 __global__ void bce_logits_kernel(const float* __restrict__ x, float* __restrict__ dx, float* __restrict__ loss, long long n, float target, float scale) {
@@ -997,8 +1062,8 @@ int vsr_launch_wgrad_reduce_s2(const float* slab, int nwg, int slab_stride, floa
 
 int vsr_launch_up2_fwd(int dtype, const void* a, const void* b, void* out, int N, int H, int W, int C, hipStream_t st) {
     if (!a || !out || N < 1 || H < 1 || W < 1 || (C & 7)) return VSR_ERR_BADARG;
-    if (N > 65535 || 2 * H > 65535) return VSR_ERR_UNSUPPORTED;
-    const dim3 grid(cdiv(pm_ws(2 * W) * 32 * (C / 8), 256), 2 * H, N);
+    if (N > 65535 || H > 65535) return VSR_ERR_UNSUPPORTED;
+    const dim3 grid(cdiv(pm_ws(W) * 32 * (C / 8), 256), H, N);
     if (dtype == VSR_BF16) hipLaunchKernelGGL(up2_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, N, H, W, C);
     else if (dtype == VSR_F32) hipLaunchKernelGGL(up2_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, H, W, C);
     else return VSR_ERR_BADARG;
@@ -1039,15 +1104,30 @@ extern "C" {
 
 int vsr_spectral_norm(const float* w_orig, float* u, float* v, float* w_out, float* sigma, int rows, int cols, int training, void* stream) {
     if (!w_orig || !u || !v || !w_out || !sigma || rows < 1 || rows > 512 || cols < 1) return VSR_ERR_BADARG;
-    hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_orig, u, v, w_out, sigma, rows, cols, training, 1e-12f);
+    hipStream_t st = (hipStream_t)stream;
+    if (!training) {             // eval: u, v untouched; one workgroup is plenty off the training path
+        hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, st, w_orig, u, v, w_out, sigma, rows, cols, 0, 1e-12f);
+        HIP_CHECK_RET(hipGetLastError());
+        return VSR_OK;
+    }
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, st, w_orig, (const float*)u, v, rows, cols);
+    hipLaunchKernelGGL(sn_norm_kernel, dim3(1), dim3(1024), 0, st, v, cols, 1e-12f, (float*)nullptr);
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w_orig, (const float*)v, u, rows, cols);
+    hipLaunchKernelGGL(sn_norm_kernel, dim3(1), dim3(1024), 0, st, u, rows, 1e-12f, sigma);
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(wgrid((long long)rows * cols)), dim3(256), 0, st, w_orig, (const float*)sigma, w_out, (long long)rows * cols);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
 
 int vsr_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v, const float* sigma, float* dw_orig,
-                               int rows, int cols, void* stream) {
-    if (!dw || !w_orig || !u || !v || !sigma || !dw_orig || rows < 1 || cols < 1) return VSR_ERR_BADARG;
-    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dw, w_orig, u, v, sigma, dw_orig, rows, cols);
+                               int rows, int cols, float* scratch, void* stream) {
+    if (!dw || !w_orig || !u || !v || !sigma || !dw_orig || !scratch || rows < 1 || cols < 1) return VSR_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)rows * cols;
+    int parts = (int)((n + 256 * 64 - 1) / (256 * 64));
+    if (parts > VSR_SN_SCRATCH_FLOATS) parts = VSR_SN_SCRATCH_FLOATS;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(parts), dim3(256), 0, st, dw, w_orig, scratch, n);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(wgrid(n)), dim3(256), 0, st, dw, u, v, sigma, (const float*)scratch, parts, dw_orig, rows, cols);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

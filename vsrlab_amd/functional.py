@@ -622,11 +622,12 @@ class _DiscriminatorFn(torch.autograd.Function):
         grads = [None] * 12
         if any_p:
             grads[0], grads[1], grads[10], grads[11] = geff[0], geff[1], geff[10], geff[11]
+            sn_scratch = torch.empty(1024, dtype=torch.float32, device=dout.device)      # VSR_SN_SCRATCH_FLOATS
             for k, (co, ci, ks) in enumerate(_DISC_SPECTRAL):
                 gorig = torch.zeros_like(p32[2 + k])
                 u, v = ctx.uv[k]
                 _lib.check(lib.vsr_spectral_norm_backward(_ptr(geff[2 + k]), _ptr(p32[2 + k]), _ptr(u), _ptr(v), _ptr(ctx.sig[k]),
-                                                          _ptr(gorig), co, ci * ks * ks, _stream()), "spectral_norm_backward")
+                                                          _ptr(gorig), co, ci * ks * ks, _ptr(sn_scratch), _stream()), "spectral_norm_backward")
                 grads[2 + k] = gorig
         ctx.ws = None
         return (dimg, None, None, None) + tuple(g if need_p[k] else None for k, g in enumerate(grads)) + (None,) * 16
