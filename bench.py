@@ -307,12 +307,11 @@ def main():
                                 "achieved_GBs_per_gpu": round(bpf * frames_per_s / world / 1e9, 1),
                                 "hbm_frac": round(bpf * frames_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                                 "achieved_TFLOPs_per_gpu": round(fpf * frames_per_s / world / 1e12, 1)}
-        if world == 1:
-            if args.dtype == "bf16":
-                out["roofline"] = dominant_kernel_roofline(dev, h, w)
-                log(f"dominant kernel: {out['roofline']['avg_us']} us")
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(h, w)
+        if args.dtype == "bf16":                             # the dominant kernel's leg: rank 0's GPU, after the timed region, at every N
+            out["roofline"] = dominant_kernel_roofline(dev, h, w)
+            log(f"dominant kernel: {out['roofline']['avg_us']} us")
+        if world == 1 and not args.no_cpu_baseline:          # the CPU baseline: rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(h, w)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
