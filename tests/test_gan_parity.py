@@ -127,6 +127,43 @@ def test_unet_discriminator_vs_golden(dtype):
         _noise_floor_check(got, emu, ref, max_glob_ratio=1.5, max_tensor_ratio=2.5)
 
 
+def test_discriminator_bf16_many_tiles_per_workgroup():
+    """conv_wide2 is persistent: at config 3 a workgroup walks ~125 tiles, at the golden's 32x48 frames exactly one.  Here the
+    workgroups per output column are capped at 3 (VSRLAB_AMD_WIDE2_MAX_WG, a test knob), so on a (1,3,72,136) frame every wide layer
+    runs several tiles per workgroup (ragged ones included): tile-to-tile DMA ring, epilogue drain, K-split reduction.  bf16 vs the
+    fp64 oracle with the noise-floor criterion."""
+    dev = _gpu()
+    import os
+    from test_hip_parity import _noise_floor_check
+    os.environ["VSRLAB_AMD_WIDE2_MAX_WG"] = "3"
+    try:
+        d = _make_d(dev, "bf16")
+        img = rand(21, 1, 3, 72, 136).to(dev).requires_grad_(True)
+        cot = rand(22, 1, 1, 72, 136, lo=-1, hi=1).to(dev)
+        out = d(img)
+        torch.mean(out * cot).backward()
+    finally:
+        del os.environ["VSRLAB_AMD_WIDE2_MAX_WG"]
+    sd = {k: v.double() for k, v in O.keyed_state_dict(D.disc_param_shapes(3, 64)).items()}
+    leaves = {k: v.clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in sd.items()}
+    img64 = rand(21, 1, 3, 72, 136).double().requires_grad_(True)
+    out64 = D.discriminator_forward(leaves, img64, True)
+    torch.mean(out64 * cot.cpu().double()).backward()
+    named = dict(d.named_parameters())
+    ref = {k: v.grad for k, v in leaves.items() if v.requires_grad}
+    got = {k: named[k].grad.detach().cpu() for k in ref}
+    got["__dimg"], ref["__dimg"] = img.grad.detach().cpu(), img64.grad
+    lv = {k: v.float().clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in sd.items()}
+    img_e = rand(21, 1, 3, 72, 136).requires_grad_(True)
+    with O.emulate_bf16():
+        out_e = D.discriminator_forward(lv, img_e, True)
+        torch.mean(out_e * cot.cpu()).backward()
+    emu = {k: v.grad for k, v in lv.items() if v.requires_grad}
+    emu["__dimg"] = img_e.grad
+    assert rel_err(out, out64) <= 1.5 * max(rel_err(out_e, out64), 1e-3), (rel_err(out, out64), rel_err(out_e, out64))
+    _noise_floor_check(got, emu, ref, max_glob_ratio=1.5, max_tensor_ratio=2.5)
+
+
 def test_gan_iteration_vs_golden():
     """generator_step / discriminator_step (train_gan.py:35-58, perceptual_loss null) on fixed sr / lq / hr tensors: both
     losses, d loss_g / d sr, d loss_g / d lq, D's parameter gradients of loss_d and the u / v buffers after the three

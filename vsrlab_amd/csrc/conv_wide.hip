@@ -17,6 +17,7 @@
 // Everything here serves config 3, not the headline metric: it is built for correctness first, on the generic
 // 256-thread tile structure (two workgroups per CU), not tuned like conv3x3_persist.hip.
 #include <cmath>
+#include <cstdlib>
 #include "kernels.h"
 #include "../../include/vsrlab_hip.h"
 
@@ -988,6 +989,11 @@ int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st) {
         int nwx = vsr_num_cus() / cols;
         if (nwx < 1) nwx = 1;
         if (nwx > tiles) nwx = tiles;
+        {   // test knob: cap the workgroups per column so that small frames exercise the many-tiles-per-workgroup path
+            const char* e = getenv("VSRLAB_AMD_WIDE2_MAX_WG");
+            const int cap = e ? atoi(e) : 0;
+            if (cap > 0 && nwx > cap) nwx = cap;
+        }
         static VsrDevOnce once2, once2k;
         if (ks) {
             { const int rc = vsr_set_max_dynamic_lds(once2k, reinterpret_cast<const void*>(conv_wide2_kernel<true>), W2_LDS); if (rc != VSR_OK) return rc; }
