@@ -26,6 +26,34 @@ def test_state_dict_matches_reference_keys_and_shapes():
     assert all(("spynet" in k) == (not p.requires_grad) for k, p in m.named_parameters())
 
 
+def test_parameter_containers_match_the_reference_generated_schema():
+    """tests/golden/state_dict_schema.json is written by make_golden.py from the REFERENCE's own modules (keys, shapes, dtypes,
+    requires_grad): the vsrlab_amd containers must carry exactly that schema, so a reference checkpoint loads with strict=True."""
+    import importlib
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_schema.json")) as f:
+        schema = json.load(f)
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
+    from vsrlab_amd.vsr.models.VRT.modules.spynet import SpyNet
+    disc = importlib.import_module("vsrlab_amd.vsr.models.RealBasicVSR.modules.unet-discriminator").UNetDiscriminator
+    built = {
+        "BasicVSR(64,30,4,False,False)": BasicVSR(64, 30, 4, False, False),
+        "RealBasicVSR(20,mid_channels=64,upscale=4,res_blocks=20)": RealBasicVSR(20, mid_channels=64, upscale=4, res_blocks=20,
+                                                                                  pretrained_flow=False, train_flow=False),
+        "UNetDiscriminator(3,64)": disc(3, 64),
+        "VRT.SpyNet(pretrained=False)": SpyNet(pretrained=False),
+    }
+    assert set(built) == set(schema)
+    for name, m in built.items():
+        want = schema[name]
+        req = {k: bool(p.requires_grad) for k, p in m.named_parameters()}
+        got = {k: {"shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""), "requires_grad": req.get(k)} for k, v in m.state_dict().items()}
+        assert set(got) == set(want), (name, sorted(set(got) ^ set(want))[:6])
+        for k in want:
+            assert got[k] == want[k], (name, k, got[k], want[k])
+
+
 def test_realbasicvsr_surface_and_keys():
     from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
     m = RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2, pretrained_flow=False, train_flow=False)
