@@ -744,24 +744,32 @@ __global__ void up2_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, 
         const int px = idx & 31, r = idx >> 5;
         const int c = r % CP, x = (r / CP) * 32 + px;
         if (x >= W) return;
+        // x2 bilinear (align_corners=False) is separable with weights (1/4, 3/4) / (3/4, 1/4); its adjoint gathers the 4 x 4 outputs
+        // 2y-1 .. 2y+2 with weights (1/4, 3/4, 3/4, 1/4) per axis.  At the border the output that clamped its missing neighbour onto this
+        // pixel carries that weight too (row 0: Y = 0 counts 1.0; row H-1: Y = 2H-1 counts 1.0): branch-free, 16 loads.
+        float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        if (y == 0) { wy[0] = 0.f; wy[1] += 0.25f; }
+        if (y == H - 1) { wy[3] = 0.f; wy[2] += 0.25f; }
+        if (x == 0) { wx[0] = 0.f; wx[1] += 0.25f; }
+        if (x == W - 1) { wx[3] = 0.f; wx[2] += 0.25f; }
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int Y = 2 * y - 1; Y <= 2 * y + 2; ++Y) {
-            if (Y < 0 || Y >= H2) continue;
-            int y0, y1; float ly;
-            up2_src(Y, H, y0, y1, ly);
-            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
-            if (wy == 0.f) continue;
-            for (int X = 2 * x - 1; X <= 2 * x + 2; ++X) {
-                if (X < 0 || X >= W2) continue;
-                int x0, x1; float lx;
-                up2_src(X, W, x0, x1, lx);
-                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-                if (wx == 0.f) continue;
-                float f[8];
-                ld8<T>(dout + (long long)n * out_img + pm_off(Y, X, c, W2, C), f);
+        const T* ob = dout + (long long)n * out_img;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (wy * wx) * f[j];
+        for (int i = 0; i < 4; ++i) {
+            int Y = 2 * y - 1 + i;
+            Y = Y < 0 ? 0 : (Y > H2 - 1 ? H2 - 1 : Y);
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int X = 2 * x - 1 + k;
+                X = X < 0 ? 0 : (X > W2 - 1 ? W2 - 1 : X);
+                float f[8];
+                ld8<T>(ob + pm_off(Y, X, c, W2, C), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] += wx[k] * f[j];
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wy[i] * t[j];
         }
         const long long o = (long long)n * in_img + pm_off(y, x, c, W, C);
         if (din) st8<T>(din + o, acc);
