@@ -305,6 +305,7 @@ constexpr int LW_XS = 36;                                              // slots 
 constexpr int LW_ROW = 8 * LW_XS * 16, LW_TILE = (LT_H + 2) * LW_ROW;  // 4,608 / 46,080 bytes
 constexpr int LW_SLOTS = LW_TILE / 16, LW_NPIECE = LW_SLOTS / 64;      // 2,880 slots = 45 DMA pieces
 constexpr int LW_NPIECE_W = (LW_NPIECE + 3) / 4;                       // 12 per producer wave
+constexpr int LW_DY = 3 * LT_H * LT_W * 4;                             // 3,072 bytes: the dY tile of the ring kernel
 __device__ __forceinline__ s16x4_t hr_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
@@ -448,6 +449,157 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_kernel(const bf16_t* __r
     }
 }
 
+__global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dy,
+                                                               long long dy_nstride, float* __restrict__ slab, int slab_stride,
+                                                               int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char tiles[];      // ring: 3 x LW_TILE + 3 x LW_DY; reused for the final reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
+    const int i15 = lane & 15, q = lane >> 4;
+    const int ntx = cdiv(W, LT_W), nty = cdiv(H, LT_H);
+    const int total = N * ntx * nty;
+    const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
+    const long long plane = (long long)H * W;
+
+    if (role == 1) {
+        const char* src = reinterpret_cast<const char*>(x);
+        const char* zsrc = reinterpret_cast<const char*>(g_fp_zero_chunk);
+        const int WSs = pm_ws(W);
+        auto issue = [&](int tile, int buf) {
+            const int n = tile / (ntx * nty), r = tile - n * (ntx * nty);
+            const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+            const char* org = src + ((long long)n * pm_image_elems(H, W, 64) + pm_off(ty0, tx0, 0, W, 64)) * 2;
+            char* dstb = tiles + buf * LW_TILE;
+#pragma unroll
+            for (int i = 0; i < LW_NPIECE_W; ++i) {
+                const int piece = w4 + 4 * i;
+                if (piece >= LW_NPIECE) break;
+                const int idx = piece * 64 + lane;           // LDS slot = [row ty][chunk c][36 slots tx] x 16 B
+                const int ty = idx / (8 * LW_XS), rem = idx - ty * (8 * LW_XS);
+                const int c = rem / LW_XS, tx = rem - c * LW_XS;
+                const int dx = tx - 1;
+                const int vy = ty0 + ty - 1, vx = tx0 + dx;
+                const char* sp = org + ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+                if (!(tx < LT_W + 2 && vy >= 0 && vy < H && vx >= 0 && vx < W)) sp = zsrc;
+                FP_GLDS16(sp, dstb + piece * 1024);
+            }
+        };
+        // dY tile [co (3)][8 rows][32 px] fp32 = 3 pieces of 1 KiB: piece c on producer wave c + 1 (those waves carry 11 X pieces, so every
+        // wave issues 12 DMA instructions per tile).  W is a multiple of 4 here, so a 16-byte chunk is inside the image or outside it.
+        auto issue_dy = [&](int tile, int buf) {
+            if (w4 == 0) return;
+            const int n = tile / (ntx * nty), r = tile - n * (ntx * nty);
+            const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+            const int row = lane >> 3, xc = (lane & 7) * 4;
+            const float* sp = dy + (long long)n * dy_nstride + (long long)(w4 - 1) * plane + (long long)(ty0 + row) * W + tx0 + xc;
+            const char* spc = (ty0 + row < H && tx0 + xc < W) ? reinterpret_cast<const char*>(sp) : zsrc;
+            FP_GLDS16(spc, tiles + 3 * LW_TILE + buf * LW_DY + (w4 - 1) * 1024);
+        };
+        // ring of three tile buffers, DMA two tiles ahead (the tile's work is far shorter than the loaded memory latency: two tiles in
+        // flight instead of one); at the end of tile i only tile i+1 must have landed: the 12 pieces of tile i+2 stay in flight
+        int cur = 0, tile = walk.first;
+        if (tile < walk.end) { issue(tile, 0); issue_dy(tile, 0); }
+        if (tile + walk.stride < walk.end) { issue(tile + walk.stride, 1); issue_dy(tile + walk.stride, 1); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (; tile < walk.end; tile += walk.stride) {
+            const int next2 = tile + 2 * walk.stride;
+            if (next2 < walk.end) {
+                const int b2 = cur == 0 ? 2 : cur - 1;
+                issue(next2, b2); issue_dy(next2, b2);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        __syncthreads();                                     // matches the consumers' barrier before the final reduction
+        __syncthreads();
+        return;
+    }
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[tap][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    // transposing-read address of this lane: lane 4 q4 + p of a 16-lane group supplies pixel q4, channels 4p..4p+3;
+    // the group index (= q of the MFMA operand) selects the pixel octet 8 q .. 8 q + 7 of the row
+    const int q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+    const int abase = (p4 >> 3) * (LW_XS * 16) + (8 * q + q4) * 16 + (p4 & 7) * 2;     // + mb * 2 chunks, + row, + kx
+    __syncthreads();                                         // the first tile is in LDS
+    int cur = 0;
+    for (int t = walk.first; t < walk.end; t += walk.stride) {
+        const int n = t / (ntx * nty), r = t - n * (ntx * nty);
+        const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+        // B[k = pixel 8 q + j][n = co i15] of this wave's two rows, from the dY tile the producers staged (zeros for co >= 3)
+        bf16x8_t fb[2];
+        {
+            const float* dt = reinterpret_cast<const float*>(tiles + 3 * LW_TILE + cur * LW_DY) + (i15 < 3 ? i15 : 0) * 256 + 8 * q;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float4 a0 = *reinterpret_cast<const float4*>(dt + (2 * w4 + rr) * 32), a1 = *reinterpret_cast<const float4*>(dt + (2 * w4 + rr) * 32 + 4);
+                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float vv = i15 < 3 ? v[j] : 0.f; fb[rr][j] = (bf16_t)vv; bsum += vv; }
+            }
+        }
+        const char* tb = tiles + cur * LW_TILE + abase;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const char* pa = tb + (2 * w4 + rr + tap / 3) * LW_ROW + mb * 2 * (LW_XS * 16) + (tap % 3) * 16;
+                    union { s16x4_t s[2]; bf16x8_t b; } u;
+                    u.s[0] = hr_tr_read(pa);
+                    u.s[1] = hr_tr_read(pa + 64);
+                    acc[tap][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.b, fb[rr], acc[tap][mb], 0, 0, 0);
+                }
+        hr_barrier();                                        // the producers' next tile has landed; this one is consumed
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+    // ---- sum the 4 MFMA waves through LDS (the tile buffers are free), then one slab per workgroup ----
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(tiles);            // [3 waves][144][64 lanes] fp32 = 110,592 B (of 92,160 x ... see launcher)
+    if (w4 > 0) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xch[(((w4 - 1) * 36 + tap * 4 + mb) * 4 + j) * 64 + lane] = acc[tap][mb][j];
+    }
+    float* bx = xch + 3 * 144 * 64;                          // [4 waves][64 lanes] bias partial sums
+    bx[w4 * 64 + lane] = bsum;
+    __syncthreads();
+    if (w4 == 0) {
+        float* sl = slab + (long long)blockIdx.x * slab_stride;
+        const int co = i15;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[tap][mb][j];
+#pragma unroll
+                    for (int ww = 0; ww < 3; ++ww) v += xch[((ww * 36 + tap * 4 + mb) * 4 + j) * 64 + lane];
+                    if (co < 3) sl[((long long)tap * 32 + co) * 64 + mb * 16 + 4 * q + j] = v;      // C[m = ci 4q+j][n = co]
+                }
+        if (lane < 3) {                                      // db[co]: lanes (co, q = 0..3) of the 4 waves
+            float b = 0.f;
+            for (int ww = 0; ww < 4; ++ww)
+                for (int qq = 0; qq < 4; ++qq) b += bx[ww * 64 + qq * 16 + lane];
+            sl[9 * 32 * 64 + lane] = b;
+        }
+    }
+}
+
 }  // namespace
 
 // dX (pixel-major bf16, 64 channels) = mask(aux) * dgrad of a 64 -> 3 3x3 conv, from the planar fp32 cotangent dsr
@@ -494,6 +646,14 @@ int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride,
     const int tiles = N * cdiv(W, LT_W) * cdiv(H, LT_H);
     const int grid = tiles < num_cus ? tiles : num_cus;
     *nslabs = grid;
+    if ((W & 3) == 0 && (dy_nstride & 3) == 0 && (reinterpret_cast<size_t>(dy) & 15) == 0) {     // 16-byte dY chunks: the ring kernel
+        constexpr int LDSR = 3 * LW_TILE + 3 * LW_DY;                                                // 147,456 B
+        static VsrDevOnce once_r;
+        { const int rc = vsr_set_max_dynamic_lds(once_r, reinterpret_cast<const void*>(last2_wgrad_ring_kernel), LDSR); if (rc != VSR_OK) return rc; }
+        hipLaunchKernelGGL(last2_wgrad_ring_kernel, dim3(grid), dim3(FP_NT), LDSR, st, (const bf16_t*)x, dy, dy_nstride, slab, slab_stride, N, H, W);
+        HIP_CHECK_RET(hipGetLastError());
+        return VSR_OK;
+    }
     hipLaunchKernelGGL(last2_wgrad_kernel, dim3(grid), dim3(FP_NT), LDS, st, (const bf16_t*)x, dy, dy_nstride, slab, slab_stride, N, H, W);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
