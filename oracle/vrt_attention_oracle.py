@@ -108,6 +108,31 @@ def tmsa_forward(sd: Mapping[str, Tensor], x: Tensor, mask_matrix: Optional[Tens
     return x + z
 
 
+def tmsag_forward(sd: Mapping[str, Tensor], x: Tensor, heads: int, window_size, shift_size, mut_attn: bool, depth: int) -> Tensor:
+    """TMSAG.forward (vsr/models/VRT/modules/tmsa.py:177-202): depth TMSA blocks, block i shifted iff i is odd (:168), one mask
+    computed per call from the padded volume (:186-191).  x: (B, C, D, H, W); keys blocks.{i}.*"""
+    B, C, D, H, W = x.shape
+    ws, ss = list(window_size), list(shift_size if shift_size is not None else [w // 2 for w in window_size])
+    full_ss = list(ss)
+    for i, s in enumerate((D, H, W)):                              # get_window_size on the GROUP's sizes (:185)
+        if s <= ws[i]:
+            ws[i], ss[i] = s, 0
+    Dp, Hp, Wp = -(-D // ws[0]) * ws[0], -(-H // ws[1]) * ws[1], -(-W // ws[2]) * ws[2]
+    mask = compute_mask(Dp, Hp, Wp, ws, ss).to(x.dtype)
+    y = x.permute(0, 2, 3, 4, 1)
+    for i in range(depth):
+        blk = {k[len(f"blocks.{i}."):]: v for k, v in sd.items() if k.startswith(f"blocks.{i}.")}
+        y = tmsa_forward(blk, y, mask, heads, tuple(window_size), (0, 0, 0) if i % 2 == 0 else tuple(full_ss), mut_attn)
+    return y.reshape(B, D, H, W, -1).permute(0, 4, 1, 2, 3)
+
+
+def rtmsa_forward(sd: Mapping[str, Tensor], x: Tensor, heads: int, window_size, depth: int) -> Tensor:
+    """RTMSA.forward (tmsa.py:250-251): x + linear(TMSAG(x) channels-last), the group without mutual attention (:236)."""
+    grp = {k[len("residual_group."):]: v for k, v in sd.items() if k.startswith("residual_group.")}
+    y = tmsag_forward(grp, x, heads, window_size, None, False, depth)
+    return x + F.linear(y.transpose(1, 4), sd["linear.weight"], sd["linear.bias"]).transpose(1, 4)
+
+
 def vrt_spynet_forward(sd: Mapping[str, Tensor], ref: Tensor, supp: Tensor, return_levels=(5,)):
     """SpyNet.forward / .process of the VRT tree (vsr/models/VRT/modules/spynet.py:98-157): the canonical SPyNet -- no ReLU
     after a level's last conv (:68-82), keys basic_module.{l}.basic_module.{0,2,4,6,8} -- returning the flows of the

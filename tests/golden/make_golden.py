@@ -393,6 +393,43 @@ def vrt():
     print("vrt_spynet", {k: v.shape for k, v in store.items()})
 
 
+def vrt_groups():
+    """TMSAG and RTMSA (vsr/models/VRT/modules/tmsa.py:126-251), fp64 reference: a depth-3 TMSAG with mutual attention (dim 120, 6 heads,
+    window (2,8,8), volume (4,20,16): padding in H, blocks 0 / 2 unshifted, block 1 shifted by (1,4,4)) and a depth-2 RTMSA (dim 180,
+    6 heads, window (6,8,8) on a (6,16,16) volume: the D extent equals the window, so get_window_size zeroes that shift).  Keyed parameters."""
+    torch.set_num_threads(8)
+    import_reference()
+    from vsrlab.vsr.models.VRT.modules import tmsa as ref_tmsa
+    from oracle.basicvsr_oracle import keyed_tensor
+    store = {}
+
+    def run(tag, m, shape, seeds):
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                p.copy_(keyed_tensor(k, tuple(p.shape)))
+        m = m.double()
+        x = rand(seeds[0], *shape, lo=-1, hi=1).double().requires_grad_(True)
+        cot = rand(seeds[1], *shape, lo=-1, hi=1).double()
+        y = m(x)
+        (y * cot).sum().backward()
+        store[f"{tag}__out"] = y.detach().float().numpy()
+        gx = x.grad.detach()
+        store[f"{tag}__gnorm__dx"] = np.asarray(float(gx.norm()))
+        store[f"{tag}__gproj__dx"] = np.asarray(float((gx * proj_vector("dx", tuple(gx.shape))).sum()))
+        store[f"{tag}__seed_x"], store[f"{tag}__seed_cot"] = np.asarray(seeds[0]), np.asarray(seeds[1])
+        store[f"{tag}__keys"] = np.asarray(sorted(m.state_dict().keys()))
+        for k, p in m.named_parameters():
+            g = p.grad.detach()
+            name = k.replace(".", "__")
+            store[f"{tag}__gnorm__{name}"] = np.asarray(float(g.norm()))
+            store[f"{tag}__gproj__{name}"] = np.asarray(float((g * proj_vector(k, tuple(g.shape))).sum()))
+
+    run("g", ref_tmsa.TMSAG(120, (4, 20, 16), 3, 6, window_size=[2, 8, 8], mut_attn=True, mlp_ratio=2., qkv_bias=True), (1, 120, 4, 20, 16), (91, 92))
+    run("r", ref_tmsa.RTMSA(180, (6, 16, 16), 2, 6, window_size=[6, 8, 8], mlp_ratio=2., qkv_bias=True), (1, 180, 6, 16, 16), (93, 94))
+    np.savez_compressed(os.path.join(HERE, "vrt_groups.npz"), **store)
+    print("vrt_groups", len(store))
+
+
 def schema():
     """state_dict keys, shapes and requires_grad flags of the reference's own modules at the BASELINE configurations, as JSON
     (data only): BasicVSR(64, 30, 4) (configs[1]), RealBasicVSR(20 cleaning blocks, mid 64, 20 residual blocks) (configs[2]),
@@ -415,8 +452,11 @@ def schema():
     dump("UNetDiscriminator(3,64)", mod.UNetDiscriminator(3, 64))
     from vsrlab.vsr.models.VRT.modules import spynet as vrt_spy
     dump("VRT.SpyNet(pretrained=False)", vrt_spy.SpyNet(pretrained=False))
+    from vsrlab.vsr.models.VRT.modules import tmsa as ref_tmsa
+    dump("TMSAG(120,(4,20,16),3,6,[2,8,8])", ref_tmsa.TMSAG(120, (4, 20, 16), 3, 6, window_size=[2, 8, 8], mut_attn=True, mlp_ratio=2., qkv_bias=True))
+    dump("RTMSA(180,(6,16,16),2,6,[6,8,8])", ref_tmsa.RTMSA(180, (6, 16, 16), 2, 6, window_size=[6, 8, 8], mlp_ratio=2., qkv_bias=True))
     with open(os.path.join(HERE, "state_dict_schema.json"), "w") as f:
-        json.dump(out, f, indent=0, sort_keys=True)
+        json.dump(out, f, separators=(",", ":"), sort_keys=True)
     print("state_dict_schema.json:", {k: len(v) for k, v in out.items()})
 
 
@@ -426,6 +466,8 @@ if __name__ == "__main__":
         schema()
     if which in ("all", "vrt"):
         vrt()
+    if which in ("all", "vrt_groups"):
+        vrt_groups()
     if which in ("all", "disc"):
         disc()
     if which in ("all", "realtrain"):

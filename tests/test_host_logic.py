@@ -36,6 +36,7 @@ def test_parameter_containers_match_the_reference_generated_schema():
     from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
     from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
     from vsrlab_amd.vsr.models.VRT.modules.spynet import SpyNet
+    from vsrlab_amd.vsr.models.VRT.modules.tmsa import RTMSA, TMSAG
     disc = importlib.import_module("vsrlab_amd.vsr.models.RealBasicVSR.modules.unet-discriminator").UNetDiscriminator
     built = {
         "BasicVSR(64,30,4,False,False)": BasicVSR(64, 30, 4, False, False),
@@ -43,6 +44,8 @@ def test_parameter_containers_match_the_reference_generated_schema():
                                                                                   pretrained_flow=False, train_flow=False),
         "UNetDiscriminator(3,64)": disc(3, 64),
         "VRT.SpyNet(pretrained=False)": SpyNet(pretrained=False),
+        "TMSAG(120,(4,20,16),3,6,[2,8,8])": TMSAG(120, (4, 20, 16), 3, 6, window_size=[2, 8, 8], mut_attn=True, mlp_ratio=2., qkv_bias=True),
+        "RTMSA(180,(6,16,16),2,6,[6,8,8])": RTMSA(180, (6, 16, 16), 2, 6, window_size=[6, 8, 8], mlp_ratio=2., qkv_bias=True),
     }
     assert set(built) == set(schema)
     for name, m in built.items():

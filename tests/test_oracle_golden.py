@@ -310,6 +310,43 @@ def test_vrt_window_attention_and_tmsa_vs_reference():
     assert _vrt_check("t", g, {k: v.grad for k, v in leaves.items() if v.is_floating_point() and v.requires_grad}) == 17
 
 
+def _group_sd(module):
+    """keyed parameters (fp64) + the module's own deterministic buffers, from this repo's CPU-constructible container"""
+    sd = {}
+    named = dict(module.named_parameters())
+    for k, v in module.state_dict().items():
+        sd[k] = O.keyed_tensor(k, tuple(v.shape)).double() if k in named else (v.double() if v.is_floating_point() else v)
+    return sd
+
+
+def test_vrt_tmsag_and_rtmsa_vs_reference():
+    """oracle tmsag_forward / rtmsa_forward against the reference's fp64 TMSAG (depth 3, mutual attention, padded volume, block 1
+    shifted) and RTMSA (depth 2, window (6,8,8) on a volume whose D equals the window): output, d/dx and every parameter gradient
+    by norm and seeded projection; the state_dict keys of this repo's containers equal the reference's."""
+    from helpers import proj_vector
+    from oracle import vrt_attention_oracle as V
+    from vsrlab_amd.vsr.models.VRT.modules.tmsa import RTMSA, TMSAG
+    g = golden("vrt_groups")
+    raw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vrt_groups.npz"))
+    cases = (("g", TMSAG(120, (4, 20, 16), 3, 6, window_size=[2, 8, 8], mut_attn=True, mlp_ratio=2., qkv_bias=True), (1, 120, 4, 20, 16),
+              lambda sd, x: V.tmsag_forward(sd, x, 6, (2, 8, 8), None, True, 3)),
+             ("r", RTMSA(180, (6, 16, 16), 2, 6, window_size=[6, 8, 8], mlp_ratio=2., qkv_bias=True), (1, 180, 6, 16, 16),
+              lambda sd, x: V.rtmsa_forward(sd, x, 6, (6, 8, 8), 2)))
+    for tag, module, shape, fwd in cases:
+        assert sorted(module.state_dict().keys()) == [str(k) for k in raw[f"{tag}__keys"]]
+        sd = _group_sd(module)
+        named = dict(module.named_parameters())
+        leaves = {k: (v.clone().requires_grad_(True) if k in named else v) for k, v in sd.items()}
+        x = rand(int(g[f"{tag}__seed_x"]), *shape, lo=-1, hi=1).double().requires_grad_(True)
+        cot = rand(int(g[f"{tag}__seed_cot"]), *shape, lo=-1, hi=1).double()
+        y = fwd(leaves, x)
+        (y * cot).sum().backward()
+        assert rel_err(y, g[f"{tag}__out"]) < 1e-6
+        grads = {k: v.grad for k, v in leaves.items() if k in named}
+        grads["dx"] = x.grad
+        assert _vrt_check(tag, g, grads) == len(named) + 1
+
+
 def _vrt_spynet_sd():
     from vsrlab_amd.vsr.models.VRT.modules.spynet import SpyNet
     m = SpyNet(False, [2, 3, 4, 5])

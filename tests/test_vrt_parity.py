@@ -121,6 +121,54 @@ def test_tmsa_block_vs_golden():
     assert n == 17
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tmsag_and_rtmsa_vs_golden(dtype):
+    """The two containers around TMSA (tmsa.py:126-251) with the HIP attention inside: TMSAG depth 3 with mutual attention on a padded
+    volume (block 1 shifted, one mask per call) and RTMSA depth 2 on (6,8,8) windows (N = 384 keys in registers).  fp32 build: output,
+    d/dx and every parameter gradient (norm + seeded projection) against the reference's fp64 run at 1e-3; bf16 build: output and
+    d/dx error <= 1.5 x the error of the bf16-emulating oracle."""
+    dev = _gpu()
+    from vsrlab_amd.vsr.models.VRT.modules.tmsa import RTMSA, TMSAG
+    g = golden("vrt_groups")
+    cases = (("g", lambda: TMSAG(120, (4, 20, 16), 3, 6, window_size=[2, 8, 8], mut_attn=True, mlp_ratio=2., qkv_bias=True), (1, 120, 4, 20, 16),
+              lambda sd, x: V.tmsag_forward(sd, x, 6, (2, 8, 8), None, True, 3)),
+             ("r", lambda: RTMSA(180, (6, 16, 16), 2, 6, window_size=[6, 8, 8], mlp_ratio=2., qkv_bias=True), (1, 180, 6, 16, 16),
+              lambda sd, x: V.rtmsa_forward(sd, x, 6, (6, 8, 8), 2)))
+    for tag, make, shape, fwd in cases:
+        m = _keyed(make()).to(dev)
+        for mod in m.modules():
+            if hasattr(mod, "compute_dtype"):
+                mod.compute_dtype = dtype
+        x = rand(int(g[f"{tag}__seed_x"]), *shape, lo=-1, hi=1).to(dev).requires_grad_(True)
+        cot = rand(int(g[f"{tag}__seed_cot"]), *shape, lo=-1, hi=1).to(dev)
+        y = m(x)
+        (y * cot).sum().backward()
+        if dtype == "fp32":
+            assert rel_err(y, g[f"{tag}__out"]) < 1e-3
+            grads = {k: p.grad for k, p in m.named_parameters()}
+            grads["dx"] = x.grad
+            for k, gr in grads.items():
+                name = k.replace(".", "__")
+                gn = float(g[f"{tag}__gnorm__{name}"])
+                assert abs(float(gr.norm()) - gn) < 1e-3 * gn, (tag, k)
+                assert abs(float((gr.cpu().double() * proj_vector(k, tuple(gr.shape))).sum()) - float(g[f"{tag}__gproj__{name}"])) < 1e-3 * gn * gr.numel() ** 0.5, (tag, k)
+        else:
+            cpu = make()
+            _keyed(cpu)
+            named = dict(cpu.named_parameters())
+            sd = {k: (v.detach().clone() if k in named else v) for k, v in cpu.state_dict().items()}
+            x64 = rand(int(g[f"{tag}__seed_x"]), *shape, lo=-1, hi=1).double().requires_grad_(True)
+            y64 = fwd({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x64)
+            (y64 * cot.cpu().double()).sum().backward()
+            assert rel_err(y64, g[f"{tag}__out"]) < 1e-6
+            xe = rand(int(g[f"{tag}__seed_x"]), *shape, lo=-1, hi=1).requires_grad_(True)
+            with O.emulate_bf16():
+                ye = fwd(sd, xe)
+                (ye * cot.cpu()).sum().backward()
+            assert rel_err(y, y64) <= 1.5 * max(rel_err(ye, y64), 1e-3), (tag, rel_err(y, y64), rel_err(ye, y64))
+            assert rel_err(x.grad, x64.grad) <= 1.5 * max(rel_err(xe.grad, x64.grad), 1e-3), (tag, rel_err(x.grad, x64.grad), rel_err(xe.grad, x64.grad))
+
+
 def test_window_attention_config5_scale_properties():
     """BASELINE config 5's stage-1 shape through the C ABI (bf16): 320x180 LR padded to 320x184, 16 frames, window (2,8,8)
     -> 7360 windows x 128 tokens, dim 120, 6 heads.  Size-independent properties: with v == 1 every output is 1 (softmax

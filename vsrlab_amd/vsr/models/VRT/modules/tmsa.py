@@ -1,12 +1,14 @@
 """``TMSA`` -- Temporal Mutual Self Attention block (vsrlab ``src/vsr/models/VRT/modules/tmsa.py:9-124``), with the
-HIP window attention inside.  Same constructor, parameter names (``norm1``, ``attn.*``, ``norm2``, ``mlp.*``) and
-``forward(x, mask_matrix)`` on (B, D, H, W, C).  ``drop_path`` > 0 (stochastic depth) is a training-time regulariser
+HIP window attention inside, and its two containers ``TMSAG`` (``tmsa.py:126-202``: depth blocks, every second one
+shifted, one attention mask per call) and ``RTMSA`` (``tmsa.py:204-251``: residual TMSAG without mutual attention + a
+linear layer).  Same constructors, parameter names (``norm1``, ``attn.*``, ``norm2``, ``mlp.*``; ``blocks.{i}.*``;
+``residual_group.*``, ``linear.*``) and forwards.  ``drop_path`` > 0 (stochastic depth) is a training-time regulariser
 outside the hot path and is not offered."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .window_attention import Mlp_GEGLU, WindowAttention, get_window_size, window_partition, window_reverse
+from .window_attention import Mlp_GEGLU, WindowAttention, compute_mask, get_window_size, window_partition, window_reverse
 
 
 class TMSA(nn.Module):
@@ -58,3 +60,48 @@ class TMSA(nn.Module):
         x = x + self.forward_part1(x, mask_matrix)
         x = x + self.forward_part2(x)
         return x
+
+
+class TMSAG(nn.Module):
+    """Temporal Mutual Self Attention Group (tmsa.py:126-202).  forward(x): (B, C, D, H, W) -> (B, C, D, H, W)."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size=[6, 8, 8], shift_size=None, mut_attn=True, mlp_ratio=2.,
+                 qkv_bias=False, qk_scale=None, drop_path=0., norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.window_size = window_size
+        self.shift_size = list(i // 2 for i in window_size) if shift_size is None else shift_size
+        self.blocks = nn.ModuleList([
+            TMSA(dim=dim, input_resolution=input_resolution, num_heads=num_heads, window_size=tuple(window_size),
+                 shift_size=(0, 0, 0) if i % 2 == 0 else tuple(self.shift_size), mut_attn=mut_attn, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                 qk_scale=qk_scale, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path, norm_layer=norm_layer)
+            for i in range(depth)])
+
+    def forward(self, x):
+        B, C, D, H, W = x.shape
+        window_size, shift_size = get_window_size((D, H, W), tuple(self.window_size), tuple(self.shift_size))
+        x = x.permute(0, 2, 3, 4, 1)
+        Dp = -(-D // window_size[0]) * window_size[0]
+        Hp = -(-H // window_size[1]) * window_size[1]
+        Wp = -(-W // window_size[2]) * window_size[2]
+        attn_mask = compute_mask(Dp, Hp, Wp, window_size, shift_size, x.device).type_as(x)      # one mask for all shifted blocks (:191)
+        for blk in self.blocks:
+            x = blk(x, attn_mask)
+        return x.reshape(B, D, H, W, -1).permute(0, 4, 1, 2, 3)
+
+
+class RTMSA(nn.Module):
+    """Residual Temporal Mutual Self Attention (tmsa.py:204-251): x + linear(TMSAG(x)) with self attention only."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=2., qkv_bias=True, qk_scale=None, drop_path=0.,
+                 norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.residual_group = TMSAG(dim=dim, input_resolution=input_resolution, depth=depth, num_heads=num_heads, window_size=window_size,
+                                    mut_attn=False, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop_path=drop_path,
+                                    norm_layer=norm_layer)
+        self.linear = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return x + self.linear(self.residual_group(x).transpose(1, 4)).transpose(1, 4)
