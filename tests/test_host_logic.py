@@ -151,6 +151,9 @@ def test_hydra_target_alias_and_instantiate():
         assert "conv_3.conv.weight_orig" in d.state_dict() and "conv_3.conv.weight_u" in d.state_dict()
         wa = importlib.import_module("vsrlab.vsr.models.VRT.modules.window_attention")
         assert hasattr(wa, "WindowAttention") and hasattr(wa, "compute_mask")
+        grp = vsrlab_amd.instantiate({"_target_": "vsrlab.vsr.models.VRT.modules.tmsa.RTMSA", "dim": 120, "input_resolution": [2, 8, 8],
+                                      "depth": 2, "num_heads": 6, "window_size": [2, 8, 8]})     # tmsa.py:204-251
+        assert "residual_group.blocks.1.attn.qkv_self.weight" in grp.state_dict() and "linear.bias" in grp.state_dict()
     finally:
         for k in [k for k in sys.modules if k == "vsrlab" or k.startswith("vsrlab.")]:
             del sys.modules[k]
