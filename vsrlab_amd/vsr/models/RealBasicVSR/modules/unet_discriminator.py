@@ -12,22 +12,21 @@ from ..... import functional as VF
 from .....core.modules.conv import SpectralConv
 
 
+_SPECTRAL_LAYERS = ((1, 1, 2, 4, 2), (2, 2, 4, 4, 2), (3, 4, 8, 4, 2), (4, 8, 4, 3, 1), (5, 4, 2, 3, 1), (6, 2, 1, 3, 1), (7, 1, 1, 3, 1), (8, 1, 1, 3, 1))
+
+
 class UNetDiscriminator(nn.Module):
     def __init__(self, in_ch=3, mid_ch=64):
         super().__init__()
         if in_ch != 3 or mid_ch != 64:
             raise NotImplementedError("the HIP discriminator is built for in_ch=3, mid_ch=64 (conf/train/gan.yaml:18-19)")
+        # parameter containers only (the arithmetic is in csrc/disc_engine.hip); attribute names = the reference's state_dict keys.
+        # (k, in multiple, out multiple, kernel, stride) of the eight spectrally normalised convs: three 4x4 stride-2 down, three 3x3 up, two 3x3 at 64
         self.conv_0 = nn.Conv2d(in_ch, mid_ch, 3, 1, 1)
-        self.conv_1 = SpectralConv(mid_ch, mid_ch * 2, 4, 2, 1)
-        self.conv_2 = SpectralConv(mid_ch * 2, mid_ch * 4, 4, 2, 1)
-        self.conv_3 = SpectralConv(mid_ch * 4, mid_ch * 8, 4, 2, 1)
-        self.conv_4 = SpectralConv(mid_ch * 8, mid_ch * 4, 3, 1, 1)
-        self.conv_5 = SpectralConv(mid_ch * 4, mid_ch * 2, 3, 1, 1)
-        self.conv_6 = SpectralConv(mid_ch * 2, mid_ch, 3, 1, 1)
-        self.conv_7 = SpectralConv(mid_ch, mid_ch, 3, 1, 1)
-        self.conv_8 = SpectralConv(mid_ch, mid_ch, 3, 1, 1)
+        for k, cin, cout, ks, stride in _SPECTRAL_LAYERS:
+            setattr(self, f"conv_{k}", SpectralConv(mid_ch * cin, mid_ch * cout, ks, stride, 1))
         self.conv_9 = nn.Conv2d(mid_ch, 1, 3, 1, 1)
-        self.upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)
+        self.upsample = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)     # parameter-free; kept for attribute compatibility
         self.lrelu = nn.LeakyReLU(0.2)
         #: 'fp32' | 'bf16' | None (= bf16 under autocast, else fp32; $VSRLAB_AMD_DTYPE overrides)
         self.compute_dtype = None
