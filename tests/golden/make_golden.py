@@ -393,6 +393,29 @@ def vrt():
     print("vrt_spynet", {k: v.shape for k, v in store.items()})
 
 
+def vrt_helpers():
+    """Deterministic index / buffer helpers of window_attention.py (:9-77, :164-188) as data: relative position index, sine position
+    encoding, shift masks (incl. zero shifts along an axis), get_window_size results."""
+    import_reference()
+    from vsrlab.vsr.models.VRT.modules import window_attention as R
+    store = {}
+    for name, ws in (("a", (2, 8, 8)), ("b", (6, 8, 8)), ("c", (3, 5, 7))):
+        m = R.WindowAttention(120, ws, 6, True, None, True)
+        store[f"{name}__ws"] = np.asarray(ws)
+        store[f"{name}__index"] = m.relative_position_index.numpy().astype(np.int32)
+        store[f"{name}__sine"] = m.position_bias.numpy()
+    for i, (D, H, W, ws, ss) in enumerate(((4, 24, 16, (2, 8, 8), (1, 4, 4)), (6, 16, 16, (6, 8, 8), (0, 4, 4)), (4, 16, 16, (2, 8, 8), (1, 0, 4)),
+                                           (2, 8, 8, (2, 8, 8), (0, 0, 0)))):
+        store[f"m{i}__args"] = np.asarray((D, H, W) + ws + ss)
+        store[f"m{i}__mask"] = R.compute_mask(D, H, W, ws, ss, "cpu").numpy().astype(np.int8)
+    for i, (xs, ws, ss) in enumerate((((4, 20, 16), (2, 8, 8), (1, 4, 4)), ((6, 16, 16), (6, 8, 8), (3, 4, 4)), ((2, 8, 9), (2, 8, 8), (1, 4, 4)))):
+        u, v = R.get_window_size(xs, ws, ss)
+        store[f"w{i}__args"] = np.asarray(xs + ws + ss)
+        store[f"w{i}__out"] = np.asarray(tuple(u) + tuple(v))
+    np.savez_compressed(os.path.join(HERE, "vrt_helpers.npz"), **store)
+    print("vrt_helpers", len(store))
+
+
 def vrt_groups():
     """TMSAG and RTMSA (vsr/models/VRT/modules/tmsa.py:126-251), fp64 reference: a depth-3 TMSAG with mutual attention (dim 120, 6 heads,
     window (2,8,8), volume (4,20,16): padding in H, blocks 0 / 2 unshifted, block 1 shifted by (1,4,4)) and a depth-2 RTMSA (dim 180,
@@ -466,6 +489,8 @@ if __name__ == "__main__":
         schema()
     if which in ("all", "vrt"):
         vrt()
+    if which in ("all", "vrt_helpers"):
+        vrt_helpers()
     if which in ("all", "vrt_groups"):
         vrt_groups()
     if which in ("all", "disc"):

@@ -57,6 +57,30 @@ def test_parameter_containers_match_the_reference_generated_schema():
             assert got[k] == want[k], (name, k, got[k], want[k])
 
 
+def test_vrt_window_helpers_equal_the_references():
+    """relative position index, sine position encoding (bit-exact), shift masks (incl. axes with zero shift) and get_window_size of
+    vsrlab_amd's window_attention module against tests/golden/vrt_helpers.npz (written from the reference's functions)."""
+    import numpy as np
+    from vsrlab_amd.vsr.models.VRT.modules import window_attention as M
+    g = np.load(os.path.join(ROOT, "tests", "golden", "vrt_helpers.npz"))
+    for name in ("a", "b", "c"):
+        ws = tuple(int(v) for v in g[f"{name}__ws"])
+        assert np.array_equal(M.WindowAttention.get_position_index(ws).numpy(), g[f"{name}__index"])
+        assert np.array_equal(M.WindowAttention.get_sine_position_encoding(ws[1:], 60, normalize=True).numpy(), g[f"{name}__sine"])
+    for i in range(4):
+        a = [int(v) for v in g[f"m{i}__args"]]
+        mask = M.compute_mask(a[0], a[1], a[2], tuple(a[3:6]), tuple(a[6:9]), "cpu")
+        assert mask.dtype == torch.float32 and np.array_equal(mask.numpy().astype(np.int8), g[f"m{i}__mask"])
+    for i in range(3):
+        a = [int(v) for v in g[f"w{i}__args"]]
+        u, v = M.get_window_size(tuple(a[0:3]), tuple(a[3:6]), tuple(a[6:9]))
+        assert list(u) + list(v) == [int(x) for x in g[f"w{i}__out"]]
+    x = torch.randn(2, 4, 16, 16, 5)
+    win = M.window_partition(x, (2, 8, 8))
+    assert win.shape == (2 * 2 * 2 * 2, 128, 5) and torch.equal(M.window_reverse(win.view(-1, 2, 8, 8, 5), (2, 8, 8), 2, 4, 16, 16), x)
+    assert torch.equal(win[3, 9], x[0, 0, 8 + 1, 8 + 1])           # window (0, 1, 1), token (0, 1, 1)
+
+
 def test_realbasicvsr_surface_and_keys():
     from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
     m = RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2, pretrained_flow=False, train_flow=False)

@@ -28,38 +28,29 @@ class TMSA(nn.Module):
         self.mlp = Mlp_GEGLU(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
 
     def forward_part1(self, x, mask_matrix):
+        """norm1 -> pad the volume to whole windows -> (cyclic shift) -> windows -> attention -> back (tmsa.py:60-105)"""
         B, D, H, W, C = x.shape
-        window_size, shift_size = get_window_size((D, H, W), self.window_size, self.shift_size)
-        x = self.norm1(x)
-        pad_d1 = (window_size[0] - D % window_size[0]) % window_size[0]
-        pad_b = (window_size[1] - H % window_size[1]) % window_size[1]
-        pad_r = (window_size[2] - W % window_size[2]) % window_size[2]
-        x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b, 0, pad_d1), mode='constant')
-        _, Dp, Hp, Wp, _ = x.shape
-        if any(i > 0 for i in shift_size):
-            shifted_x = torch.roll(x, shifts=(-shift_size[0], -shift_size[1], -shift_size[2]), dims=(1, 2, 3))
-            attn_mask = mask_matrix
-        else:
-            shifted_x, attn_mask = x, None
-        x_windows = window_partition(shifted_x, window_size)
-        attn_windows = self.attn(x_windows, mask=attn_mask)
-        attn_windows = attn_windows.view(-1, *(window_size + (C,)))
-        shifted_x = window_reverse(attn_windows, window_size, B, Dp, Hp, Wp)
-        if any(i > 0 for i in shift_size):
-            x = torch.roll(shifted_x, shifts=(shift_size[0], shift_size[1], shift_size[2]), dims=(1, 2, 3))
-        else:
-            x = shifted_x
-        if pad_d1 > 0 or pad_r > 0 or pad_b > 0:
-            x = x[:, :D, :H, :W, :]
-        return x
+        win, shift = get_window_size((D, H, W), self.window_size, self.shift_size)
+        y = self.norm1(x)
+        pad = [(-extent) % w for extent, w in zip((D, H, W), win)]              # trailing padding per axis
+        if any(pad):
+            y = F.pad(y, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+        Dp, Hp, Wp = D + pad[0], H + pad[1], W + pad[2]
+        shifted = any(sh > 0 for sh in shift)
+        if shifted:
+            y = torch.roll(y, shifts=tuple(-sh for sh in shift), dims=(1, 2, 3))
+        out = self.attn(window_partition(y, win), mask=mask_matrix if shifted else None)
+        y = window_reverse(out.view(-1, *win, C), win, B, Dp, Hp, Wp)
+        if shifted:
+            y = torch.roll(y, shifts=tuple(shift), dims=(1, 2, 3))
+        return y[:, :D, :H, :W, :] if any(pad) else y
 
     def forward_part2(self, x):
         return self.mlp(self.norm2(x))
 
     def forward(self, x, mask_matrix):
         x = x + self.forward_part1(x, mask_matrix)
-        x = x + self.forward_part2(x)
-        return x
+        return x + self.forward_part2(x)
 
 
 class TMSAG(nn.Module):

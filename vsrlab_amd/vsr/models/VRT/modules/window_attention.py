@@ -21,44 +21,50 @@ from ..... import functional as VF
 
 
 def window_partition(x, window_size):
-    """(B, D, H, W, C) -> (B*num_windows, Wd*Wh*Ww, C)."""
-    B, D, H, W, C = x.shape
-    x = x.view(B, D // window_size[0], window_size[0], H // window_size[1], window_size[1], W // window_size[2], window_size[2], C)
-    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous().view(-1, reduce(mul, window_size), C)
+    """(B, D, H, W, C) -> (B * windows, tokens per window, C): window-major, tokens in (d, h, w) order  (window_attention.py:9-24)."""
+    B, C = x.shape[0], x.shape[-1]
+    wd, wh, ww = window_size
+    nd, nh, nw = x.shape[1] // wd, x.shape[2] // wh, x.shape[3] // ww
+    tiles = x.reshape(B, nd, wd, nh, wh, nw, ww, C).permute(0, 1, 3, 5, 2, 4, 6, 7)     # (B, nd, nh, nw, wd, wh, ww, C)
+    return tiles.reshape(B * nd * nh * nw, wd * wh * ww, C)
 
 
 def window_reverse(windows, window_size, B, D, H, W):
-    """(B*num_windows, Wd, Wh, Ww, C) -> (B, D, H, W, C)."""
-    x = windows.view(B, D // window_size[0], H // window_size[1], W // window_size[2], window_size[0], window_size[1], window_size[2], -1)
-    return x.permute(0, 1, 4, 2, 5, 3, 6, 7).contiguous().view(B, D, H, W, -1)
+    """inverse of window_partition: (B * windows, wd, wh, ww, C) -> (B, D, H, W, C)  (:26-42)."""
+    wd, wh, ww = window_size
+    nd, nh, nw = D // wd, H // wh, W // ww
+    tiles = windows.reshape(B, nd, nh, nw, wd, wh, ww, -1).permute(0, 1, 4, 2, 5, 3, 6, 7)
+    return tiles.reshape(B, D, H, W, -1)
 
 
 def get_window_size(x_size, window_size, shift_size=None):
-    use_window_size = list(window_size)
-    use_shift_size = list(shift_size) if shift_size is not None else None
-    for i in range(len(x_size)):
-        if x_size[i] <= window_size[i]:
-            use_window_size[i] = x_size[i]
-            if shift_size is not None:
-                use_shift_size[i] = 0
+    """An axis not longer than its window is ONE window and is not shifted  (:44-59)."""
+    fits = [extent <= win for extent, win in zip(x_size, window_size)]
+    used = tuple(extent if f else win for extent, win, f in zip(x_size, window_size, fits))
     if shift_size is None:
-        return tuple(use_window_size)
-    return tuple(use_window_size), tuple(use_shift_size)
+        return used
+    return used, tuple(0 if f else sh for sh, f in zip(shift_size, fits))
+
+
+def _axis_regions(length, win, shift, device):
+    """region label (0, 1, 2) of every position along one axis of the cyclically shifted volume: [0, L-win) | [L-win, L-shift) | [L-shift, L);
+    with shift 0 the last region is the whole axis (what the reference's `slice(-0, None)` assignment leaves behind)"""
+    pos = torch.arange(length, device=device)
+    if shift == 0:
+        return torch.full_like(pos, 2)
+    return (pos >= length - win).long() + (pos >= length - shift).long()
 
 
 @lru_cache()
 def compute_mask(D, H, W, window_size, shift_size, device):
-    """Attention mask of the shifted windows: 0 inside a region, -100 across regions."""
-    img_mask = torch.zeros((1, D, H, W, 1), device=device)
-    cnt = 0
-    for d in slice(-window_size[0]), slice(-window_size[0], -shift_size[0]), slice(-shift_size[0], None):
-        for h in slice(-window_size[1]), slice(-window_size[1], -shift_size[1]), slice(-shift_size[1], None):
-            for w in slice(-window_size[2]), slice(-window_size[2], -shift_size[2]), slice(-shift_size[2], None):
-                img_mask[:, d, h, w, :] = cnt
-                cnt += 1
-    mask_windows = window_partition(img_mask, window_size).squeeze(-1)
-    attn_mask = mask_windows.unsqueeze(1) - mask_windows.unsqueeze(2)
-    return attn_mask.masked_fill(attn_mask != 0, float(-100.0)).masked_fill(attn_mask == 0, float(0.0))
+    """Attention mask of the shifted windows: 0 between tokens of the same region, -100 across regions  (:61-77)."""
+    rd = _axis_regions(D, window_size[0], shift_size[0], device)
+    rh = _axis_regions(H, window_size[1], shift_size[1], device)
+    rw = _axis_regions(W, window_size[2], shift_size[2], device)
+    region = ((rd[:, None, None] * 3 + rh[None, :, None]) * 3 + rw[None, None, :]).to(torch.float32).reshape(1, D, H, W, 1)
+    per_window = window_partition(region, window_size).squeeze(-1)                        # (windows, tokens)
+    differs = per_window[:, None, :] != per_window[:, :, None]
+    return torch.where(differs, torch.full((), -100.0, device=device), torch.zeros((), device=device))
 
 
 class Mlp_GEGLU(nn.Module):
@@ -113,35 +119,36 @@ class WindowAttention(nn.Module):
 
     @staticmethod
     def get_position_index(window_size):
-        coords = torch.stack(torch.meshgrid(torch.arange(window_size[0]), torch.arange(window_size[1]), torch.arange(window_size[2]),
-                                            indexing="ij"))
-        coords_flatten = torch.flatten(coords, 1)
-        relative_coords = (coords_flatten[:, :, None] - coords_flatten[:, None, :]).permute(1, 2, 0).contiguous()
-        relative_coords[:, :, 0] += window_size[0] - 1
-        relative_coords[:, :, 1] += window_size[1] - 1
-        relative_coords[:, :, 2] += window_size[2] - 1
-        relative_coords[:, :, 0] *= (2 * window_size[1] - 1) * (2 * window_size[2] - 1)
-        relative_coords[:, :, 1] *= (2 * window_size[2] - 1)
-        return relative_coords.sum(-1)
+        """index into the bias table for every (query token, key token) pair of a window: the offset (dd, dh, dw) of the two tokens, each
+        shifted to >= 0, in row-major order over (2 wd - 1, 2 wh - 1, 2 ww - 1)  (:164-179)"""
+        wd, wh, ww = window_size
+        d = torch.arange(wd).repeat_interleave(wh * ww)
+        h = torch.arange(wh).repeat_interleave(ww).repeat(wd)
+        w = torch.arange(ww).repeat(wd * wh)
+        off = lambda v, n: v[:, None] - v[None, :] + (n - 1)            # noqa: E731
+        return (off(d, wd) * (2 * wh - 1) + off(h, wh)) * (2 * ww - 1) + off(w, ww)
 
     @staticmethod
     def get_sine_position_encoding(HW, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        """2-D sine / cosine encoding of the (h, w) position of a window token, (1, H*W, 2 * num_pos_feats): y features first, even feature
+        = sin, odd = cos, both of position / temperature^(2 (j // 2) / num_pos_feats)  (:181-188 and the helper it calls)"""
         if scale is not None and normalize is False:
             raise ValueError("normalize should be True if scale is passed")
-        if scale is None:
-            scale = 2 * math.pi
-        not_mask = torch.ones([1, HW[0], HW[1]])
-        y_embed = not_mask.cumsum(1, dtype=torch.float32)
-        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        scale = 2 * math.pi if scale is None else scale
+        H, W = HW
+        ys = torch.arange(1, H + 1, dtype=torch.float32)
+        xs = torch.arange(1, W + 1, dtype=torch.float32)
         if normalize:
-            eps = 1e-6
-            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
-            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
-        dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
-        dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
-        pos_x = x_embed[:, :, :, None] / dim_t
-        pos_y = y_embed[:, :, :, None] / dim_t
-        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        pos_embed = torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
-        return pos_embed.flatten(2).permute(0, 2, 1).contiguous()
+            ys = ys / (ys[-1:] + 1e-6) * scale
+            xs = xs / (xs[-1:] + 1e-6) * scale
+        j = torch.arange(num_pos_feats, dtype=torch.float32)
+        period = temperature ** (2 * (j // 2) / num_pos_feats)
+        even = (torch.arange(num_pos_feats) % 2 == 0)
+
+        def feats(p):                                                   # (L,) -> (L, num_pos_feats)
+            a = p[:, None] / period
+            return torch.where(even, a.sin(), a.cos())
+
+        fy = feats(ys)[:, None, :].expand(H, W, num_pos_feats)
+        fx = feats(xs)[None, :, :].expand(H, W, num_pos_feats)
+        return torch.cat((fy, fx), dim=2).reshape(1, H * W, 2 * num_pos_feats).contiguous()
