@@ -10,8 +10,11 @@ from ... import functional as VF
 class PixelShufflePack(nn.Module):
     def __init__(self, in_ch, out_ch, upscale_factor):
         super().__init__()
-        self.upconv = nn.Conv2d(in_ch, out_ch * upscale_factor * upscale_factor, 3, 1, 1)
-        self.pixel_shuffle = nn.PixelShuffle(upscale_factor)
+        r = int(upscale_factor)
+        if r != 2:
+            raise NotImplementedError("the HIP pixel-shuffle store pattern is built for upscale_factor 2 (BasicVSR x4 = two of them, basicvsr.py:19)")
+        self.upconv = nn.Conv2d(in_ch, out_ch * r * r, kernel_size=3, stride=1, padding=1)     # key: upconv.{weight,bias}
+        self.pixel_shuffle = nn.PixelShuffle(r)                                                # parameter-free; kept for attribute compatibility
 
     def forward(self, x):
         return VF.pixel_shuffle_pack_forward(x, self.upconv.weight, self.upconv.bias)
