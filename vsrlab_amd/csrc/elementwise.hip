@@ -255,11 +255,25 @@ __global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __r
                                     int N, int H, int W, long long flow_nstride) {
     constexpr int C = 64;
     const long long total = (long long)N * H * W;
-    for (long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pix < total; pix += (long long)gridDim.x * (blockDim.x >> 6)) {
+    const int lane = threadIdx.x & 63;
+    // a wave scans 64 consecutive pixels (one flow vector per lane, coalesced) and then serves the far ones among them -- usually none --
+    // one at a time with lane = channel (r02: one wave per pixel cost 81 us per 540p launch with nothing to do)
+    for (long long base = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; base < total; base += (long long)gridDim.x * (blockDim.x >> 6) * 64) {
+        const long long mine = base + lane;
+        float mfx = 0.f, mfy = 0.f;
+        if (mine < total) {
+            const int mn = (int)(mine / ((long long)W * H));
+            const long long hw = mine - (long long)mn * W * H;
+            const float* fq = flow + (long long)mn * flow_nstride + hw;
+            mfx = fq[0]; mfy = fq[(long long)H * W];
+        }
+        unsigned long long todo = __ballot(mine < total && flow_is_far(mfx, mfy));
+        while (todo) {
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const long long pix = base + b;
         const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
-        const float* fp = flow + (long long)n * flow_nstride + (long long)y * W + x;
-        const float fx = fp[0], fy = fp[(long long)H * W];
-        if (!flow_is_far(fx, fy)) continue;             // wave-uniform: one wave per pixel, lane = channel
+        const float fx = __shfl(mfx, b, 64), fy = __shfl(mfy, b, 64);
         const int c = threadIdx.x & 63;
         if (c == 0) atomicAdd(far_count, 1);
         const float px = warp_coord((float)x, fx, W), py = warp_coord((float)y, fy, H);
@@ -275,6 +289,7 @@ __global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __r
             const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
             const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
             if (xi >= 0 && xi < W && yi >= 0 && yi < H) atomicAdd(imgp + ((long long)yi * W + xi) * C + c, g * wgt);
+        }
         }
     }
 }
@@ -821,8 +836,9 @@ int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, c
     if (!dout || !flow || !S || !far_count || !out) return VSR_ERR_BADARG;
     const long long npix = (long long)N * H * W;
     const int tiles = N * cdiv(H, GTH) * cdiv(W, GTW);
-    long long gb = (npix + 3) / 4;
+    long long gb = (npix + 255) / 256;                      // 4 waves per block x 64 pixels per wave
     if (gb > 256 * 16) gb = 256 * 16;
+    if (gb < 1) gb = 1;
     DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_far_kernel<T>, dim3((int)gb), dim3(256), 0, st, (const T*)dout, flow, S, far_count, N, H, W, flow_nstride));
     DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_gather_kernel<T>, dim3(tiles), dim3(256), 0, st, (const T*)dout, flow, (const T*)dtop, S,
                                          (const int*)far_count, (T*)out, N, H, W, flow_nstride));
