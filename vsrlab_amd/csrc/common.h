@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define VSR_MAX_Z 4
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
-enum { MASK_NONE = 0, MASK_RELU = 1, MASK_LEAKY = 2, MASK_RELU_BITS = 3 };   // _BITS: internal to the persistent kernel
+enum { MASK_NONE = 0, MASK_RELU = 1, MASK_LEAKY = 2, MASK_RELU_BITS = 3, MASK_LEAKY_BITS = 4 };   // _BITS: internal to the persistent kernel
 enum { EPI_NHWC = 0, EPI_PLANAR = 1 };
 
 // One implicit-GEMM convolution launch (stride 1, "same" zero padding, KS x KS).

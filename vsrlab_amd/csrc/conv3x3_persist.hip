@@ -223,8 +223,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             tile_coords(tile, ntx, nty, n, ty0, tx0);
             const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oy[z], tx0 * a.out_step, 0, a.Wd, 64);
             bool ok[4];
-            constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE;   // both operands early would not fit 2 waves / SIMD
-            constexpr bool BITS = MASK == MASK_RELU_BITS;
+            constexpr bool BITS = MASK == MASK_RELU_BITS || MASK == MASK_LEAKY_BITS;
+            constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE && !BITS;   // both bf16 operands early would not fit 2 waves / SIMD
             bf4 rr[4][4], mm[4][4];                                  // [mb][nb]
             uint2 sbits = make_uint2(0u, 0u);                         // 64 sign bits of this lane's 64 outputs of the tile
             if (BITS) sbits = reinterpret_cast<const uint2*>(a.sign_bits[z])[(long long)tile * 256 + w4 * 64 + lane];
@@ -323,7 +323,11 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                             for (int j = 0; j < 4; ++j) sout[(mb * 4 + nb) >> 3] |= (v[j] > 0.f ? 1u : 0u) << ((((mb * 4 + nb) & 7) * 4) + j);
                         }
-                        if (BITS) {
+                        if (MASK == MASK_LEAKY_BITS) {
+                            const unsigned wbits = ((mb * 4 + nb) >> 3) ? sbits.y : sbits.x;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= ((wbits >> ((((mb * 4 + nb) & 7) * 4) + j)) & 1u) ? 1.f : slope;
+                        } else if (BITS) {
                             const unsigned wbits = ((mb * 4 + nb) >> 3) ? sbits.y : sbits.x;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)     // sign-extended 1-bit field = all-ones / zero mask on the float's bits
@@ -356,6 +360,36 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
         for (int k = 0; k < 8; ++k) g_stamps[(blockIdx.x * 8 + wave) * 8 + k] = st_sum[k];
 #endif
+}
+
+// Sign bits of a stored bf16 activation in THIS kernel's tile order ([tile][MFMA wave][lane] x 64 bits, bit (4 mb + nb) * 4 + j = element
+// cout 16 mb + 4 q + j of pixel (row 2 w4 + (nb >> 1), column 16 (nb & 1) + pxl)): for activations produced by another kernel (the trunk
+// stem runs on the generic two-source kernel) whose mask a persistent data-gradient launch needs.  66 MB read, 4 MB written at 540p.
+__global__ void sign_bits_c64_kernel(const bf16_t* __restrict__ x, uint2* __restrict__ bits, int N, int H, int W) {
+    const int ntx = cdiv(W, PTW), nty = cdiv(H, PTH);
+    const long long total = (long long)N * ntx * nty * 256;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int lane = (int)(gid & 63), w4 = (int)((gid >> 6) & 3);
+    const int tile = (int)(gid >> 8);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int pxl = (l15 >= 4 && l15 < 12) ? 2 * (l15 - 4) : (l15 < 4 ? 2 * l15 + 1 : 2 * (l15 - 8) + 1);
+    int n, ty0, tx0;
+    tile_coords(tile, ntx, nty, n, ty0, tx0);
+    unsigned out[2] = {0u, 0u};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int yy = ty0 + 2 * w4 + (nb >> 1), xx = tx0 + (nb & 1) * 16 + pxl;
+        if (yy < H && xx < W) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const bf4 v = *reinterpret_cast<const bf4*>(x + (long long)n * pm_image_elems(H, W, 64) + pm_off(yy, xx, 2 * mb + (q >> 1), W, 64) + 4 * (q & 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[(mb * 4 + nb) >> 3] |= ((float)v.v[j] > 0.f ? 1u : 0u) << ((((mb * 4 + nb) & 7) * 4) + j);
+            }
+        }
+    }
+    bits[gid] = make_uint2(out[0], out[1]);
 }
 
 template <int ACT, bool HAS_RES, int MASK>
@@ -393,6 +427,11 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
         for (int z = 0; z < a.nz; ++z) bits = bits && a.sign_bits[z];
         if (bits) mask = MASK_RELU_BITS;
     }
+    if (mask == MASK_LEAKY && res) {                       // (dgrad + dX) * LeakyReLU': the mask from sign bits keeps the residual prefetch
+        bool bits = true;
+        for (int z = 0; z < a.nz; ++z) bits = bits && a.sign_bits[z];
+        if (bits) mask = MASK_LEAKY_BITS;
+    }
     if (pm_image_elems((PTHH + 2) * a.in_step, a.Ws, 64) * 2 > 0x7fffffffLL || pm_image_elems(2 * PTH + 2, a.Wd, 64) > 0x7fffffffLL)
         return VSR_ERR_UNSUPPORTED;                                                  // in-tile offsets are 32-bit
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
@@ -403,7 +442,17 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     PERSIST_CASE(ACT_NONE, false, MASK_RELU)     // dgrad(conv2) * ReLU'
     PERSIST_CASE(ACT_NONE, false, MASK_RELU_BITS)   // the same, from the sign bits the bias+ReLU launch left (4 MB instead of 66 MB)
     PERSIST_CASE(ACT_NONE, true, MASK_LEAKY)     // (dgrad(conv1 of block 0) + dX) * LeakyReLU' of the stem
+    PERSIST_CASE(ACT_NONE, true, MASK_LEAKY_BITS)   // the same with the stem's sign bits (vsr_launch_sign_bits_c64): no late 66 MB mask read
     PERSIST_CASE(ACT_NONE, false, MASK_LEAKY)    // dgrad * LeakyReLU' (discriminator conv_7 / conv_8)
 #undef PERSIST_CASE
     return VSR_ERR_UNSUPPORTED;
+}
+
+// bits: N * ceil(H/8) * ceil(W/32) * 256 uint2 (the size the engine reserves for a persistent launch's sign_out)
+int vsr_launch_sign_bits_c64(const void* x_pm, void* bits, int N, int H, int W, hipStream_t st) {
+    if (!x_pm || !bits || N < 1 || H < 1 || W < 1) return VSR_ERR_BADARG;
+    const long long total = (long long)N * cdiv(W, PTW) * cdiv(H, PTH) * 256;
+    hipLaunchKernelGGL(sign_bits_c64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x_pm, (uint2*)bits, N, H, W);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
 }

@@ -106,6 +106,8 @@ struct Plan {
     // reconstruction
     std::vector<size_t> Pt, U0, U1, C0;
     std::vector<size_t> SBC0;                   // sign bits of C0 = LeakyReLU(conv_last.0) per frame (bf16 build, training)
+    std::vector<size_t> SBPt;                   // sign bits of Pt = LeakyReLU(point_conv) per frame (bf16 build, training)
+    std::vector<size_t> SBX0[2];                // sign bits of the stem outputs X_0 (bf16 build, training): mask of the block-0 data gradient
     // backward
     std::vector<size_t> G0[2], G1[2], DX[2];    // G1: rb per frame, DX: (rb+1) per frame (DX[0] unused -> G0)
     std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
@@ -151,8 +153,10 @@ struct Plan {
             Wp[dir].assign(t, 0); feat[dir].assign(t, 0);
             if (bwd) {
                 X[dir].assign((size_t)t * (rb + 1), 0); A[dir].assign((size_t)t * rb, 0); SB[dir].assign((size_t)t * rb, 0);
+                SBX0[dir].assign(t, 0);
                 const size_t sbytes = dtype == VSR_BF16 ? (size_t)n * cdiv(h, 8) * cdiv(w, 32) * 2048 : 256;
                 for (int i = 0; i < t; ++i) {
+                    SBX0[dir][i] = b.take(sbytes);
                     Wp[dir][i] = b.take(a1);
                     for (int k = 0; k <= rb; ++k) X[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
                     for (int k = 0; k < rb; ++k) A[dir][(size_t)i * rb + k] = b.take(a1);
@@ -168,9 +172,12 @@ struct Plan {
         Pt.assign(t, 0); U0.assign(t, 0); U1.assign(t, 0); C0.assign(t, 0);
         for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
         for (int i = nrec; i < t; ++i) { Pt[i] = Pt[0]; U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; }
-        SBC0.assign(t, 0);
+        SBC0.assign(t, 0); SBPt.assign(t, 0);
         if (bwd && dtype == VSR_BF16)
-            for (int i = 0; i < t; ++i) SBC0[i] = b.take((size_t)n * cdiv(4 * h, 8) * cdiv(4 * w, 32) * 2048);
+            for (int i = 0; i < t; ++i) {
+                SBC0[i] = b.take((size_t)n * cdiv(4 * h, 8) * cdiv(4 * w, 32) * 2048);
+                SBPt[i] = b.take((size_t)n * cdiv(h, 8) * cdiv(w, 32) * 2048);
+            }
         if (bwd) {
             for (int dir = 0; dir < 2; ++dir) {
                 G0[dir].assign(t, 0); G1[dir].assign((size_t)t * rb, 0); DX[dir].assign((size_t)t * (rb + 1), 0);
@@ -243,7 +250,7 @@ struct Ctx {
     // four weight sets do not fit LDS together), phase z reading phase z-1's partial sum as its residual in place --
     // the partial sums pass through bf16 three times (~1.6x the rounding error of the final store alone), for
     // 560 us instead of 1470 us at 1080x1920.  fp32: one generic 4-source launch, accumulated in registers.
-    int conv_ps_dgrad(const void* dy, size_t wpackd, void* dx, const void* aux, int mask, int N, int H, int W) const {
+    int conv_ps_dgrad(const void* dy, size_t wpackd, void* dx, const void* aux, int mask, int N, int H, int W, const void* sign_bits = nullptr) const {
         if (dtype == VSR_BF16) {
             for (int z = 0; z < 4; ++z) {
                 ConvArgs a = base(N, H, W);
@@ -251,7 +258,7 @@ struct Ctx {
                 a.src[0] = dy; a.src_oy[0] = z >> 1; a.src_ox[0] = z & 1; a.src_nstride[0] = pm_image_elems(2 * H, 2 * W, C);
                 a.wpack = at(wpackd + (size_t)z * 9 * C * C * p.es); a.dst[0] = dx;
                 a.res[0] = z > 0 ? dx : nullptr;
-                if (z == 3) { a.aux[0] = aux; a.mask_mode = mask; }
+                if (z == 3) { a.aux[0] = aux; a.mask_mode = mask; a.sign_bits[0] = aux ? sign_bits : nullptr; }
                 int rc = vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
                 if (rc != VSR_OK) return rc;
             }
@@ -427,6 +434,8 @@ int trunk_forward(const Ctx& c, const Plan& p, int dir, int i, const void* warpe
         a.src[1] = lrs + (size_t)i * 3 * h * w; a.src_nstride[1] = (long long)p.t * 3 * h * w;
         a.wpack = c.at(p.stem_w[dir]); a.bias = c.fat(p.stem_b[dir]); a.dst[0] = x; a.act = ACT_LEAKY;
         CK(vsr_launch_conv(c.dtype, 3, 2, 64, 16, 1, 64, EPI_NHWC, a, c.st));
+        // the stem runs on the generic two-source kernel: its LeakyReLU sign bits for the block-0 data gradient come from a 66 MB pass
+        if (p.bwd && c.dtype == VSR_BF16) CK(vsr_launch_sign_bits_c64(x, c.at(p.SBX0[dir][i]), n, h, w, c.st));
     }
     for (int b = 0; b < rb; ++b) {      // x + conv2(relu(conv1(x)))   (conv.py:89-92)
         void* act = p.bwd ? c.at(p.aoff(dir, i, b)) : c.at(p.scratchA[dir]);
@@ -446,6 +455,7 @@ int recon_forward(const Ctx& c, const Plan& p, int i, const float* lrs, float* s
         a.src[0] = c.at(p.feat[0][i]); a.src[1] = c.at(p.feat[1][i]);
         a.wpack = c.at(p.point_w); a.bias = c.fat(p.point_b); a.dst[0] = c.at(p.Pt[i]); a.act = ACT_LEAKY;
         CK(vsr_launch_conv(c.dtype, 1, 2, 64, 64, 0, 64, EPI_NHWC, a, c.st));
+        if (p.bwd && c.dtype == VSR_BF16) CK(vsr_launch_sign_bits_c64(c.at(p.Pt[i]), c.at(p.SBPt[i]), n, h, w, c.st));   // mask of upsample.0's data gradient
     }
     CK(c.conv_ps(c.at(p.Pt[i]), p.up_w[0], c.fat(p.up_b[0]), c.at(p.U0[i]), n, h, w));
     CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), n, 2 * h, 2 * w));
@@ -680,7 +690,7 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
         CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(1)], C, 0, 4, z, g[ix.up_b(1)]));
     }
     // upsample.0 (at h x w): its input is LeakyReLU(point_conv) => mask with P
-    CK(c.conv_ps_dgrad(c.at(p.G_U0), p.up_wd[0], c.at(p.G_P), c.at(p.Pt[i]), MASK_LEAKY, n, h, w));
+    CK(c.conv_ps_dgrad(c.at(p.G_U0), p.up_wd[0], c.at(p.G_P), c.at(p.Pt[i]), MASK_LEAKY, n, h, w, c.dtype == VSR_BF16 ? c.at(p.SBPt[i]) : nullptr));
     for (int z = 0; z < 4; ++z) {
         WgradArgs a = wg_base(n, h, w);
         a.x[0] = c.at(p.Pt[i]); a.dy[0] = c.at(p.G_U0);
@@ -721,7 +731,7 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
         // dX_b = dX_{b+1} + dgrad(conv1)(dA); for b == 0 also through the stem's LeakyReLU
         void* out = b > 0 ? c.at(p.dxoff(dir, i, b)) : c.at(p.G0[dir][i]);
         CK(c.conv64(c.at(p.g1off(dir, i, b)), p.blk_wd[dir][2 * b], nullptr, out, ACT_NONE, dxn, b == 0 ? c.at(p.xoff(dir, i, 0)) : nullptr,
-                    b == 0 ? MASK_LEAKY : 0, n, h, w));
+                    b == 0 ? MASK_LEAKY : 0, n, h, w, nullptr, (b == 0 && c.dtype == VSR_BF16) ? c.at(p.SBX0[dir][i]) : nullptr));
     }
     if (has_warp)   // gradient w.r.t. the warped state (feat part of the stem's input)
         CK(c.conv64(c.at(p.G0[dir][i]), p.stem_wd[dir], nullptr, c.at(p.dWp[dir]), ACT_NONE, nullptr, nullptr, 0, n, h, w));

@@ -4,6 +4,7 @@
 
 int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar, int cout_t, int epi,
                     const ConvArgs& a, hipStream_t st);
+int vsr_launch_sign_bits_c64(const void* x_pm, void* bits, int N, int H, int W, hipStream_t st);     // conv3x3_persist.hip
 void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride);
 int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar, const WgradArgs& a, int nwg,
                      int* nslabs, hipStream_t st);      // *nslabs: partial slabs written (what the reduction sums)
