@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r2final3
+O=$GRAFT_REPO_ROOT/gpurun_out/r2final4
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -1 $O/bench_default.json | cut -c1-600 &&
