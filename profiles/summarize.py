@@ -72,7 +72,7 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in mf:
             # busy cycles are summed over the chip's 1024 SIMDs.  GRBM_GUI_ACTIVE / 8 over-reads the clock on dispatches this
             # short (MI355X_MICROARCH, DVFS give-back), so the fraction is quoted against the in-kernel clock measured with
-            # s_memtime stamps (round 1, tests/stamps_conv.py: 1.55-1.6 GHz under this load) and the trace's duration.
+            # s_memtime stamps (round 1, tools/stamps_conv.py: 1.55-1.6 GHz under this load) and the trace's duration.
             per_simd = mf["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
             mf["mfma_busy_cycles_per_simd"] = round(per_simd)
             mf["mfma_busy_frac_at_1.6GHz"] = round(per_simd / (out["roofline_leg_avg_us_rocprof"] * 1600.0), 4)

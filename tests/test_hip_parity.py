@@ -520,7 +520,7 @@ def test_basicvsr_config1_all_grads_vs_oracle(dtype):
     trainable gradient (254 tensors).  fp32 build vs the fp32 oracle (1e-3 north-star bar on sr; gradients at the
     oracle's own fp32-vs-fp64 noise floor).  bf16 build: error against the fp64 oracle <= 1.5 x the error of the
     bf16-storage-emulating oracle against the same fp64 oracle, globally; per tensor <= 2.5 x (a single tensor's
-    mask-flip noise is itself a random draw; measured worst ratio in tests/gpu_diag.py)."""
+    mask-flip noise is itself a random draw; measured worst ratio in tools/gpu_diag.py)."""
     dev = _gpu()
     shape = (2, 5, 3, 64, 64)
     m, lrs, cot, sr, grads = _run_basicvsr(dtype, 64, 30, shape, 10, 13, dev)

@@ -1,5 +1,5 @@
 """Micro-benchmark of the fused window attention at BASELINE config 5's stage shape (for rocprofv3 / PMC runs).
-    python tests/bench_attention.py [iters]   -- 7360 windows x 128 tokens, dim 120, 6 heads (head_dim 20), bf16"""
+    python tools/bench_attention.py [iters]   -- 7360 windows x 128 tokens, dim 120, 6 heads (head_dim 20), bf16"""
 import ctypes
 import os
 import sys

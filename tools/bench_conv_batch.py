@@ -1,5 +1,5 @@
 """How much of a 540p conv3x3_c64 launch is start-up / drain: time per frame when N frames share one launch.
-    python tests/bench_conv_batch.py [iters]"""
+    python tools/bench_conv_batch.py [iters]"""
 import ctypes
 import os
 import sys

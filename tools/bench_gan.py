@@ -1,6 +1,6 @@
 """BASELINE config 3 at size, for timing and rocprofv3: one GAN iteration = generator_step + backward + FusedAdam,
 discriminator_step + backward + FusedAdam (train_gan.py:35-58) on a (1,7,3,540,960) clip / seven 2160x3840 frames, bf16.
-    python tests/bench_gan.py [iters] [d|g|all]      d = discriminator step only, g = generator step only"""
+    python tools/bench_gan.py [iters] [d|g|all]      d = discriminator step only, g = generator step only"""
 import os
 import sys
 import time

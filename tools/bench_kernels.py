@@ -1,5 +1,5 @@
 """Micro-benchmark of the dominant kernels at the 540p trunk shape (for rocprofv3 / PMC runs).
-    python tests/bench_kernels.py [conv|wgrad|all] [iters]
+    python tools/bench_kernels.py [conv|wgrad|all] [iters]
 """
 import ctypes
 import os

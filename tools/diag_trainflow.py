@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helpers import GOLDEN, proj_vector, rand, rel_l2
 from oracle import basicvsr_oracle as O

@@ -1,6 +1,6 @@
 """Prints (does not assert) the error metrics of the HIP BasicVSR path against the oracle, used
 to set and justify the tolerances in test_hip_parity.py.  Run on the GPU box:
-    python tests/gpu_diag.py [rb] [t] [h] [w]
+    python tools/gpu_diag.py [rb] [t] [h] [w]
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 from helpers import rand, rel_err, rel_l2  # noqa: E402
 from oracle import basicvsr_oracle as O  # noqa: E402
 

@@ -123,6 +123,11 @@ static inline __host__ __device__ long long pm_off(int y, int x, int chunk, int 
     return (((long long)y * pm_ws(W) + seg) * (C >> 3) + chunk) * 256 + (x & 31) * 8;
 }
 
+// "Paired-block" channel order of a 64-channel MFMA output whose accumulators are 16x16 blocks (lane = pixel i + 16 q, register j
+// = row 4q + j of block mb): dealing channel pm_acc_chan(mb, row) to row `row` of block mb makes lane (i, q) hold, in blocks 2k
+// and 2k+1, the 8 consecutive channels of chunk 4k + q of its pixel = one whole 16-byte piece of the blocked layout.
+static inline __host__ __device__ int pm_acc_chan(int mb, int row) { return 8 * (4 * (mb >> 1) + (row >> 2)) + 4 * (mb & 1) + (row & 3); }
+
 // XCD-aware work split for persistent kernels: workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an
 // XCD, each with its own 4 MiB L2), so XCD x walks the x-th CONTIGUOUS eighth of the tile list: neighbouring tiles,
 // whose halos overlap, are then served by one L2.  Speed only: any placement computes every tile exactly once.

@@ -20,11 +20,17 @@
 //     (conflict-free without a swizzle), a ky shift is an immediate, and a DMA piece reads runs of up to 512
 //     contiguous bytes (a [pixel][chunk] image made every lane of a piece hit a different line:
 //     +40 % DMA issue time measured).
-//   * epilogue: the accumulator layout (lane = pixel of the segment, registers = 4 consecutive channels) IS
-//     the blocked global layout, so bias / ReLU / LeakyReLU(0.1) / residual add / activation-gradient mask /
-//     pixel-shuffle placement are applied in registers and every store (and residual / mask load) is a wave
-//     instruction over 512 contiguous bytes.  (With plain [pixel][64 ch] rows the same stores hit 32 lines
-//     per instruction and cost as much as the K loop; an LDS transposition cost 2.7 k cycles per tile.)
+//   * epilogue: the accumulator layout (lane = pixel of the segment, registers = 4 consecutive rows of a 16-row block) IS
+//     the blocked global layout once the 64 output channels are dealt to the MFMA rows in "paired-block order"
+//     (pm_acc_chan, common.h): lane (pixel i, quarter q) then holds the 8 consecutive channels of chunk 4k + q in the
+//     accumulators of blocks 2k and 2k+1, i.e. one whole 16-byte piece of the blocked layout.  Bias / ReLU / LeakyReLU(0.1) /
+//     residual add / activation-gradient mask / pixel-shuffle placement are applied in registers and every store (and
+//     residual / mask load) is a 16-byte-per-lane wave instruction over four 256-byte runs: 8 stores + 8 loads per wave and
+//     tile.  (r03: with 4 channels per lane = 16 + 16 eight-byte instructions, the vector-memory issue path, shared with
+//     the producers' 44 DMA pieces per tile, cost 1.2 k cycles per tile for the operand loads alone; with plain
+//     [pixel][64 ch] rows the stores hit 32 lines per instruction; an LDS transposition cost 2.7 k cycles per tile.)
+//     ReLU and the sign bits are computed on the PACKED bf16 words (v_pk_max_i16, v_pk_min_u16, v_lshl_or_b32: 1.5
+//     instructions per element instead of 4).
 #include "common.h"
 
 namespace {
@@ -65,6 +71,19 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define STAMP_ADD(slot, a, b)
 #endif
 
+// Diagnostic build only (make ABL=<bits>): ablations that bound what a restructuring could buy, and the in-kernel clock
+// (s_memtime / s_memrealtime around the whole kernel, lane 0 of wave 0, to a buffer of their own).  Results of an ablated
+// build are WRONG by construction; only its run time and clock are read.  bit 0: no B-fragment reads for ky = 2 (what
+// ky-shared B fragments would save); bit 1: no sign-bit output; bit 2: no A-fragment reads for ky = 2; bit 3: producers
+// issue only the first tile; bit 4: epilogue = convert + store only; bit 5: no epilogue stores; bit 6: no fragment reads
+// after step 0 (bare MFMA loop); bit 7: no lgkmcnt wait at the top of a step.
+#ifdef VSR_ABL
+__device__ unsigned long long g_clk[256 * 4];
+#define ABL(bit) ((VSR_ABL >> (bit)) & 1)
+#else
+#define ABL(bit) 0
+#endif
+
 __device__ __forceinline__ void tile_coords(int tile, int ntx, int nty, int& n, int& ty0, int& tx0) {
     const int per = ntx * nty;
     n = tile / per;
@@ -74,7 +93,17 @@ __device__ __forceinline__ void tile_coords(int tile, int ntx, int nty, int& n, 
     tx0 = (r - ty * ntx) * PTW;
 }
 
-struct __attribute__((aligned(8))) bf4 { bf16_t v[4]; };
+// two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32), low half = a
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    bf16x2_t p = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) { unsigned r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 #define GLDS16(src, dst)                                                                              \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
@@ -100,6 +129,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     char* lds_t = smem + W_BYTES;                                         // two tile buffers
+#ifdef VSR_ABL
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (tid == 0) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
     const int z = blockIdx.y;
     const int ntx = cdiv(a.W, PTW), nty = cdiv(a.H, PTH);
@@ -109,17 +142,19 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 
     // bias of this z as fp32 in LDS: the accumulators of every tile start from it (32 fewer live registers
     // than carrying it, which is what lets two waves share a SIMD)
-    if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = a.bias ? a.bias[(long long)z * a.bias_zstride + tid] : 0.f;
+    // (slot r = the channel MFMA row r of the 64 computes: paired-block order, see the epilogue)
+    if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = a.bias ? a.bias[(long long)z * a.bias_zstride + pm_acc_chan(tid >> 4, tid & 15)] : 0.f;
 
-    // ---- weights of this z: global [tap][cout][cin] -> LDS, chunk c of row r at (r*8 + (c ^ ((r>>1)&7))): the 16 rows a ds_read_b128 pass
-    // touches (same chunk, rows 16 mb .. 16 mb + 15) then fall on 16 distinct 16-byte bank groups ----
+    // ---- weights of this z: global [tap][cout][cin] -> LDS, row r = MFMA row (block r >> 4, row r & 15) holds output channel
+    // pm_acc_chan(r >> 4, r & 15); chunk c of row r at (r*8 + (c ^ ((r>>1)&7))): the 16 rows a ds_read_b128 pass touches (same
+    // chunk, rows 16 mb .. 16 mb + 15) then fall on 16 distinct 16-byte bank groups ----
     auto stage_weights = [&]() {
         const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.wpack) + (long long)z * a.w_zstride);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int idx = tid + i * PNT;                 // 4608 chunks
             const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;
-            *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[idx];
+            *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[(tap * 64 + pm_acc_chan(r >> 4, r & 15)) * 8 + c];
         }
     };
 
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         for (; tile < walk.end; tile += walk.stride) {
             STAMP(t0);
             const int next = tile + walk.stride;
-            if (next < walk.end) issue(next, cur ^ 1);
+            if (next < walk.end && !ABL(3)) issue(next, cur ^ 1);
             STAMP(p1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP(p2);
@@ -201,14 +236,14 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             a_hi[kk] = a_lo[kk] + 6 * 8192;
         }
         const int b_lane = w4 * 2 * (PTWH * 128) + q * (PTWH * 16) + pxl * 16;
-        // epilogue: accumulator block (mb, nb), register j = cout 16 mb + 4 q + j at pixel (row nb >> 1, 16 (nb & 1) + i):
-        // chunk 2 mb + (q >> 1), channels 4 (q & 1) + j of the blocked layout.  loff[nb] = lane-constant part of the
+        // epilogue: accumulator blocks (2k, nb) and (2k+1, nb), registers j = channels 8 (4k + q) + j and + 4 + j of pixel
+        // (row nb >> 1, 16 (nb & 1) + i): chunk 4k + q of the blocked layout, whole.  loff[nb] = lane-constant part of the
         // destination element offset relative to the tile's origin pm_off(ty0*os + ooy, tx0*os) (tx0*os: multiple of 32)
         int loff[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const int dx = ((nb & 1) * 16 + pxl) * a.out_step + a.out_ox[z];
-            loff[nb] = ((((w4 * 2 + (nb >> 1)) * a.out_step) * WSd + (dx >> 5)) * 8 + (q >> 1)) * 256 + (dx & 31) * 8 + 4 * (q & 1);
+            loff[nb] = ((((w4 * 2 + (nb >> 1)) * a.out_step) * WSd + (dx >> 5)) * 8 + q) * 256 + (dx & 31) * 8;
         }
         stage_weights();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -225,7 +260,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             bool ok[4];
             constexpr bool BITS = MASK == MASK_RELU_BITS || MASK == MASK_LEAKY_BITS;
             constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE && !BITS;   // both bf16 operands early would not fit 2 waves / SIMD
-            bf4 rr[4][4], mm[4][4];                                  // [mb][nb]
+            uint4 rr[2][4], mm[2][4];                                // [k][nb]: 8 channels of one pixel
             uint2 sbits = make_uint2(0u, 0u);                         // 64 sign bits of this lane's 64 outputs of the tile
             if (BITS) sbits = reinterpret_cast<const uint2*>(a.sign_bits[z])[(long long)tile * 256 + w4 * 64 + lane];
 #pragma unroll
@@ -233,10 +268,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                 ok[nb] = (tx0 + (nb & 1) * 16 + pxl < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H);
                 if (ok[nb]) {
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        const long long o = tbase + loff[nb] + mb * 512;
-                        if (HAS_RES) rr[mb][nb] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + o);
-                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[mb][nb] = *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
+                    for (int k = 0; k < 2; ++k) {
+                        const long long o = tbase + loff[nb] + k * 1024;
+                        if (HAS_RES) rr[k][nb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + o);
+                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[k][nb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
                     }
                 }
             }
@@ -257,9 +292,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);   // B base of this tile's buffer
 #define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 #define CV_LOADA(tap_, kk_, slot, mb)                                                                                  \
-            DSR(fa[slot][mb], (tap_ < 6 ? a_lo[kk_] : a_hi[kk_]), (tap_ < 6 ? tap_ : tap_ - 6) * 8192 + (mb) * 2048);
+            if (!(ABL(2) && tap_ >= 6) && !(ABL(6) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (tap_ < 6 ? a_lo[kk_] : a_hi[kk_]), (tap_ < 6 ? tap_ : tap_ - 6) * 8192 + (mb) * 2048);
 #define CV_LOADB(ky_, kx_, kk_, slot, nb)                                                                              \
-            DSR(fb[slot][nb], bb, (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
+            if (!(ABL(0) && ky_ == 2) && !(ABL(6) && ky_ + kx_ + kk_ > 0)) DSR(fb[slot][nb], bb, (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
 #define CV_LOAD(s, slot)                                                                                               \
             {                                                                                                          \
                 constexpr int tap_ = (s) / 2, kk_ = (s) % 2, ky_ = tap_ / 3, kx_ = tap_ % 3;                           \
@@ -281,7 +316,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             __builtin_amdgcn_sched_barrier(0);
 #define CV_STEP(s)                                                                                                     \
             {                                                                                                          \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* step s is in registers */                    \
+                if (!ABL(7)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* step s is in registers */        \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
                 CV_ML_A(s, 0, 0, 0) CV_ML_A(s, 0, 1, 1) CV_ML_A(s, 0, 2, 2) CV_ML_A(s, 0, 3, 3)                        \
                 CV_ML_B(s, 1, 0, 0) CV_ML_B(s, 1, 1, 1) CV_ML_B(s, 1, 2, 2) CV_ML_B(s, 1, 3, 3)                        \
@@ -305,48 +340,80 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             STAMP(t2);
 
             // ---- epilogue, entirely in registers; a store covers two 256-byte runs (two chunks x 16 pixels) per wave ----
-            unsigned sout[2] = {0u, 0u};                             // sign bits written by the bias+ReLU variant: bit (4 mb + nb) * 4 + j
+            // The residual / mask operands were requested before the K loop and have long returned, but vmcnt counts loads and
+            // stores together in issue order: hipcc's per-use waits (vmcnt(3) in every ok[nb] branch) made each store wait for
+            // the write acknowledgement of the store three before it -- ~5 exposed store latencies per tile (r03: 48 -> ~42 us
+            // per bias+skip launch).  One explicit wait here (the builtin: hipcc's scoreboard then knows the queue is empty)
+            // covers the operands; the stores after it are never waited for inside the tile.
+            if (HAS_RES || MASK != MASK_NONE) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) alone
+            // Sign bits of the tile: the lane's 64 outputs are 32 packed words wd = (4k + nb) * 4 + jj (channels 2jj, 2jj+1 of the
+            // piece); word wd owns bits (wd & 15) [even channel] and 16 + (wd & 15) [odd channel] of sout[wd >> 4].
+            unsigned sout[2] = {0u, 0u};
+            const unsigned k11 = 0x00010001u;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 if (ok[nb]) {
                     bf16_t* dst = reinterpret_cast<bf16_t*>(a.dst[z]) + tbase + loff[nb];
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        float v[4];
+                    for (int k = 0; k < 2; ++k) {
+                        float v[8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = p_act<ACT>(acc[mb][nb][j], slope);
-                        if (HAS_RES) {
+                        for (int j = 0; j < 4; ++j) { v[j] = acc[2 * k][nb][j]; v[4 + j] = acc[2 * k + 1][nb][j]; }
+                        const unsigned wbits = k ? sbits.y : sbits.x;            // words wd = 16 k + 4 nb + jj
+                        unsigned ow[4];
+                        if (ABL(4)) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += (float)rr[mb][nb].v[j];
+                            for (int jj = 0; jj < 4; ++jj) ow[jj] = pk_bf16(v[2 * jj], v[2 * jj + 1]);
+                        } else if (ACT == ACT_RELU && !HAS_RES && MASK == MASK_NONE) {
+                            // conv1 of a ResidualConv: round, then ReLU on the packed words (bf16 bit patterns order like int16
+                            // for this purpose: negative and -0 -> +0), sign bit = "the stored half is non-zero"
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                ow[jj] = pk_max_i16(pk_bf16(v[2 * jj], v[2 * jj + 1]), 0u);
+                                if (!ABL(1)) sout[k] |= pk_min_u16(ow[jj], k11) << (4 * nb + jj);
+                            }
+                        } else if (ACT == ACT_NONE && !HAS_RES && MASK == MASK_RELU_BITS) {
+                            // dgrad(conv2) * ReLU': multiply the packed halves by their 0 / 1 bits
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                ow[jj] = pk_mul_lo_u16(pk_bf16(v[2 * jj], v[2 * jj + 1]), (wbits >> (4 * nb + jj)) & k11);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = p_act<ACT>(v[j], slope);
+                            if (HAS_RES) {
+                                const unsigned rw[4] = {rr[k][nb].x, rr[k][nb].y, rr[k][nb].z, rr[k][nb].w};
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) { v[2 * jj] += bf_lo(rw[jj]); v[2 * jj + 1] += bf_hi(rw[jj]); }
+                            }
+                            if (ACT != ACT_NONE && !HAS_RES && !ABL(1)) {      // sign of the activation = sign of its argument (ReLU and LeakyReLU alike)
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) sout[k] |= (v[j] > 0.f ? 1u : 0u) << (4 * nb + (j >> 1) + 16 * (j & 1));
+                            }
+                            if (BITS) {
+                                const float neg = MASK == MASK_LEAKY_BITS ? slope : 0.f;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] *= ((wbits >> (4 * nb + (j >> 1) + 16 * (j & 1))) & 1u) ? 1.f : neg;
+                            } else if (MASK != MASK_NONE) {
+                                const float neg = MASK == MASK_LEAKY ? slope : 0.f;
+                                const uint4 mq = LATE_MASK ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[nb] + k * 1024)
+                                                           : mm[k][nb];
+                                const unsigned mw[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    v[2 * jj] *= (bf_lo(mw[jj]) > 0.f ? 1.f : neg);
+                                    v[2 * jj + 1] *= (bf_hi(mw[jj]) > 0.f ? 1.f : neg);
+                                }
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) ow[jj] = pk_bf16(v[2 * jj], v[2 * jj + 1]);
                         }
-                        if (ACT != ACT_NONE && !HAS_RES) {      // sign of the activation = sign of its argument (ReLU and LeakyReLU alike)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) sout[(mb * 4 + nb) >> 3] |= (v[j] > 0.f ? 1u : 0u) << ((((mb * 4 + nb) & 7) * 4) + j);
-                        }
-                        if (MASK == MASK_LEAKY_BITS) {
-                            const unsigned wbits = ((mb * 4 + nb) >> 3) ? sbits.y : sbits.x;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] *= ((wbits >> ((((mb * 4 + nb) & 7) * 4) + j)) & 1u) ? 1.f : slope;
-                        } else if (BITS) {
-                            const unsigned wbits = ((mb * 4 + nb) >> 3) ? sbits.y : sbits.x;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)     // sign-extended 1-bit field = all-ones / zero mask on the float's bits
-                                v[j] = __uint_as_float(__float_as_uint(v[j]) & (unsigned)__builtin_amdgcn_sbfe((int)wbits, (((mb * 4 + nb) & 7) * 4) + j, 1));
-                        } else if (MASK != MASK_NONE) {
-                            const float neg = MASK == MASK_LEAKY ? slope : 0.f;
-                            const bf4 mv = LATE_MASK ? *reinterpret_cast<const bf4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[nb] + mb * 512)
-                                                     : mm[mb][nb];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] *= ((float)mv.v[j] > 0.f ? 1.f : neg);
-                        }
-                        bf4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o.v[j] = (bf16_t)v[j];
-                        *reinterpret_cast<bf4*>(dst + mb * 512) = o;
+                        const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                        if (!ABL(5)) *reinterpret_cast<uint4*>(dst + k * 1024) = o;
+                        else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
             }
-            if (ACT != ACT_NONE && !HAS_RES && a.sign_out[z])
+            if (ACT != ACT_NONE && !HAS_RES && a.sign_out[z] && !ABL(1))
                 reinterpret_cast<uint2*>(a.sign_out[z])[(long long)tile * 256 + w4 * 64 + lane] = make_uint2(sout[0], sout[1]);
             STAMP(t3);
             __syncthreads();                               // the producers' next tile has landed; everybody has finished reading `cur`
@@ -355,6 +422,12 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
         }
     }
+#ifdef VSR_ABL
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+        g_clk[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_clk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 #ifdef VSR_STAMPS
     st_sum[0] = stamp() - st_begin;
     if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
@@ -362,9 +435,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #endif
 }
 
-// Sign bits of a stored bf16 activation in THIS kernel's tile order ([tile][MFMA wave][lane] x 64 bits, bit (4 mb + nb) * 4 + j = element
-// cout 16 mb + 4 q + j of pixel (row 2 w4 + (nb >> 1), column 16 (nb & 1) + pxl)): for activations produced by another kernel (the trunk
-// stem runs on the generic two-source kernel) whose mask a persistent data-gradient launch needs.  66 MB read, 4 MB written at 540p.
+// Sign bits of a stored bf16 activation in THIS kernel's tile order ([tile][MFMA wave][lane] x 64 bits; the lane's piece (k, nb) =
+// chunk 4k + q of pixel (row 2 w4 + (nb >> 1), column 16 (nb & 1) + pxl), its packed word jj = channels 2jj, 2jj+1: bits
+// 4 nb + jj and 16 + 4 nb + jj of word k): for activations produced by another kernel (the trunk stem runs on the generic
+// two-source kernel) whose mask a persistent data-gradient launch needs.  66 MB read, 4 MB written at 540p.
 __global__ void sign_bits_c64_kernel(const bf16_t* __restrict__ x, uint2* __restrict__ bits, int N, int H, int W) {
     const int ntx = cdiv(W, PTW), nty = cdiv(H, PTH);
     const long long total = (long long)N * ntx * nty * 256;
@@ -382,10 +456,12 @@ __global__ void sign_bits_c64_kernel(const bf16_t* __restrict__ x, uint2* __rest
         const int yy = ty0 + 2 * w4 + (nb >> 1), xx = tx0 + (nb & 1) * 16 + pxl;
         if (yy < H && xx < W) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const bf4 v = *reinterpret_cast<const bf4*>(x + (long long)n * pm_image_elems(H, W, 64) + pm_off(yy, xx, 2 * mb + (q >> 1), W, 64) + 4 * (q & 1));
+            for (int k = 0; k < 2; ++k) {
+                const uint4 v = *reinterpret_cast<const uint4*>(x + (long long)n * pm_image_elems(H, W, 64) + pm_off(yy, xx, 4 * k + q, W, 64));
+                const unsigned vw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[(mb * 4 + nb) >> 3] |= ((float)v.v[j] > 0.f ? 1u : 0u) << ((((mb * 4 + nb) & 7) * 4) + j);
+                for (int jj = 0; jj < 4; ++jj)
+                    out[k] |= ((bf_lo(vw[jj]) > 0.f ? 1u : 0u) | (bf_hi(vw[jj]) > 0.f ? 0x10000u : 0u)) << (4 * nb + jj);
             }
         }
     }
@@ -408,6 +484,11 @@ static int launch_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
 
 }  // namespace
 
+#ifdef VSR_ABL
+extern "C" int vsr_debug_read_clk(unsigned long long* host_out) {      // [256 workgroups][cycles, 100 MHz ticks, -, -] of the last launch
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clk), sizeof(unsigned long long) * 256 * 4) == hipSuccess ? 0 : -3;
+}
+#endif
 #ifdef VSR_STAMPS
 extern "C" int vsr_debug_read_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : -3;

@@ -22,9 +22,12 @@ __device__ __forceinline__ void hr_barrier() {
 // operand gathered from the fp32 dSR tile in LDS (k = 3 tap + c) and the A operand (flipped weights) built once per
 // workgroup from the fp32 OIHW tensor.  Output / mask addressing is the blocked pixel-major layout of common.h.
 // grid: persistent over 8x32-pixel tiles; block 256 = 4 waves, wave w covers tile rows 2w, 2w+1.
-// sign_bits (optional): the activation's signs as conv3x3_c64_persist_kernel left them, [tile][wave][lane] x 8 bytes (bit
-// (4 mb + nb) * 4 + j): this kernel uses the SAME tile decomposition and the same lane -> pixel permutation, so a lane reads
-// its own 64 bits (4 MB per 540p-sized tile set) instead of 16 x 8 bytes of the bf16 activation (the whole 1.06 GB C0 at HR).
+// The 64 input channels are dealt to the MFMA rows in paired-block order (pm_acc_chan, common.h), so a lane holds whole 16-byte
+// pieces of the blocked layout: 8 sixteen-byte stores per wave and tile.
+// sign_bits (optional): the activation's signs as conv3x3_c64_persist_kernel left them, [tile][wave][lane] x 8 bytes (piece
+// (k, nb), packed word jj: bits 4 nb + jj and 16 + 4 nb + jj of word k): this kernel uses the SAME tile decomposition, channel
+// order and lane -> pixel permutation, so a lane reads its own 64 bits (4 MB per 540p-sized tile set) instead of 8 x 16 bytes
+// of the bf16 activation (the whole 1.06 GB C0 at HR).
 __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restrict__ dsr, long long dsr_nstride,
                                                             const float* __restrict__ w, const bf16_t* __restrict__ aux,
                                                             const uint2* __restrict__ sign_bits, float neg,
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
         boff[j] = k < 27 ? c * LT_PL + ky * LT_RS + kx : -1;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const int ci = mb * 16 + l15;                    // A rows are indexed by the lane column itself
+            const int ci = pm_acc_chan(mb, l15);             // A rows are indexed by the lane column itself; paired-block channel order
             fa[mb][j] = (bf16_t)(k < 27 ? w[((long long)c * 64 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.f);
         }
     }
@@ -88,17 +91,17 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
         const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
         const long long obase = (long long)n * pm_image_elems(H, W, 64) + pm_off(ty0, tx0, 0, W, 64);
         // mask operands first: their latency hides behind the staging of the next tile and the MFMAs
-        bf4_t mm[4][4];
+        uint4 mm[2][4];
         bool ok[4];
         int loff[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const int row = 2 * w4 + (nb >> 1), px = (nb & 1) * 16 + i15;
             ok[nb] = ty0 + row < H && tx0 + px < W;
-            loff[nb] = (row * pm_ws(W) * 8 + (q >> 1)) * 256 + px * 8 + 4 * (q & 1);
+            loff[nb] = (row * pm_ws(W) * 8 + q) * 256 + px * 8;
             if (aux && !sign_bits && ok[nb]) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) mm[mb][nb] = *reinterpret_cast<const bf4_t*>(aux + obase + loff[nb] + mb * 512);
+                for (int k = 0; k < 2; ++k) mm[k][nb] = *reinterpret_cast<const uint4*>(aux + obase + loff[nb] + k * 1024);
             }
         }
         uint2 sb = make_uint2(0u, 0u);
@@ -124,20 +127,26 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
         for (int nb = 0; nb < 4; ++nb) {
             if (!ok[nb]) continue;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                bf4_t o;
+            for (int k = 0; k < 2; ++k) {
+                float v[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[mb][nb][j];
-                    if (sign_bits) {
-                        const unsigned wbits = ((mb * 4 + nb) >> 3) ? sb.y : sb.x;
-                        v *= ((wbits >> ((((mb * 4 + nb) & 7) * 4) + j)) & 1u) ? 1.f : neg;
-                    } else if (aux) {
-                        v *= ((float)mm[mb][nb].v[j] > 0.f ? 1.f : neg);
+                for (int j = 0; j < 4; ++j) { v[j] = acc[2 * k][nb][j]; v[4 + j] = acc[2 * k + 1][nb][j]; }
+                if (sign_bits) {
+                    const unsigned wbits = k ? sb.y : sb.x;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= ((wbits >> (4 * nb + (j >> 1) + 16 * (j & 1))) & 1u) ? 1.f : neg;
+                } else if (aux) {
+                    const unsigned mw[4] = {mm[k][nb].x, mm[k][nb].y, mm[k][nb].z, mm[k][nb].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float m = __uint_as_float((j & 1) ? (mw[j >> 1] & 0xffff0000u) : (mw[j >> 1] << 16));
+                        v[j] *= (m > 0.f ? 1.f : neg);
                     }
-                    o.v[j] = (bf16_t)v;
                 }
-                *reinterpret_cast<bf4_t*>(dst + obase + loff[nb] + mb * 512) = o;
+                bf16x8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x8_t*>(dst + obase + loff[nb] + k * 1024) = o;
             }
         }
         if (tn < total) stage_store(sv, buf ^ 1);            // the other buffer: nobody reads it during this tile
