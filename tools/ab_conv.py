@@ -23,7 +23,7 @@ def main():
     rounds = int(sys.argv[1])
     names = sys.argv[2:]
     libs = [ctypes.CDLL(os.path.join(ROOT, "vsrlab_amd", "lib", n)) for n in names]
-    h, w, nsets, iters = 540, 960, 8, 48
+    h, w, nsets, iters = 540, 960, 8, 96
     dev = torch.device("cuda:0")
     shape = (1, h, (w + 31) // 32, 8, 32, 8)
     xs = [torch.randn(shape, device=dev).to(torch.bfloat16) for _ in range(nsets)]

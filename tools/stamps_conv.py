@@ -27,8 +27,8 @@ for res, act, name in ((None, 1, "bias+relu"), (r, 0, "bias+res")):
     assert lib.vsr_debug_read_stamps(out.ctypes.data_as(P)) == 0
     s = out.reshape(256, 8, 8).astype(np.float64)
     print(f"[{name}] s_memtime ticks (100 MHz), mean over 256 CUs; whole loop incl. prologue wait: {s[:, :, 0].mean():.0f}")
-    for role, waves, slots in (("MFMA waves", slice(0, 4), ((1, "epilogue operand loads"), (2, "K loop"), (3, "epilogue"), (4, "barrier"))),
-                               ("DMA waves", slice(4, 8), ((5, "issue next tile"), (6, "vmcnt(0)"), (7, "barrier")))):
+    for role, waves, slots in (("MFMA waves", slice(0, 4), ((1, "epilogue operand loads"), (2, "K loop"), (3, "epilogue"), (4, "barrier"), (5, "prologue (once)"), (6, "  weight staging + set-up"))),
+                               ("DMA waves", slice(4, 8), ((5, "issue next tile"), (6, "vmcnt(0)"), (7, "barrier"), (2, "prologue: start -> first tile issued"), (1, "  of which: until the issue starts"), (4, "  vmcnt(0)")))):
         for k, nm in slots:
             v = s[:, waves, k]
             print(f"   {role:10s} {nm:24s} mean {v.mean():8.0f}  min {v.min():8.0f}  max {v.max():8.0f}")

@@ -95,6 +95,8 @@ __device__ __forceinline__ void tile_coords(int tile, int ntx, int nty, int& n, 
 
 // two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32), low half = a
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;     // a 16-byte piece (native vector: usable behind address-space pointers)
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     bf16x2_t p = {(bf16_t)a, (bf16_t)b};
     return __builtin_bit_cast(unsigned, p);
@@ -112,8 +114,27 @@ __device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) { unsi
 // Epilogue variants are compile-time: a runtime-selected epilogue serialises 16 load->use->store
 // chains per tile (measured: 14 us of a 71 us launch).
 template <int ACT, bool HAS_RES, int MASK>
-__global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvArgs ka) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // Every kernel argument the kernel uses, requested in ONE batch at the top and pinned in scalar registers: hipcc otherwise
+    // loads arguments lazily, next to their first use, and the producers' way to the first DMA piece went through three
+    // dependent s_load + lgkmcnt(0) rounds on the (cold) kernarg segment (r03 stamps: 3.0 k cycles from the start of the
+    // launch to the first piece; the first tile is the critical path of the prologue).
+    const int z = blockIdx.y;
+    struct {
+        int N, H, W, Ws, Wd, in_step, out_step, src_ox0, src_oy0, out_oxz, out_oyz, bias_zstride;
+        long long src_nstride0, dst_nstride, w_zstride;
+        unsigned long long src0, wpack, resz, auxz, sign_bitsz, dstz, sign_outz, bias; float leaky_slope;   // pointers as integers: GP() below
+    } a = {ka.N, ka.H, ka.W, ka.Ws, ka.Wd, ka.in_step, ka.out_step, ka.src_ox[0], ka.src_oy[0], ka.out_ox[z], ka.out_oy[z], ka.bias_zstride,
+           ka.src_nstride[0], ka.dst_nstride, ka.w_zstride,
+           (unsigned long long)ka.src[0], (unsigned long long)ka.wpack, (unsigned long long)ka.res[z], (unsigned long long)ka.aux[z],
+           (unsigned long long)ka.sign_bits[z], (unsigned long long)ka.dst[z], (unsigned long long)ka.sign_out[z], (unsigned long long)ka.bias, ka.leaky_slope};
+    asm volatile("" : "+s"(a.N), "+s"(a.H), "+s"(a.W), "+s"(a.Ws), "+s"(a.Wd), "+s"(a.in_step), "+s"(a.out_step), "+s"(a.src_ox0), "+s"(a.src_oy0),
+                 "+s"(a.out_oxz), "+s"(a.out_oyz), "+s"(a.bias_zstride), "+s"(a.src_nstride0), "+s"(a.dst_nstride), "+s"(a.w_zstride));
+    asm volatile("" : "+s"(a.src0), "+s"(a.wpack), "+s"(a.resz), "+s"(a.auxz), "+s"(a.sign_bitsz), "+s"(a.dstz), "+s"(a.sign_outz), "+s"(a.bias), "+s"(a.leaky_slope));
+    // a pinned pointer comes back as an integer: name its address space, or hipcc addresses it with flat_ instructions
+#define GP(T, x) ((__attribute__((address_space(1))) T*)(x))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2);            // 0: MFMA + epilogue, 1: LDS-DMA producer
     const int w4 = wave & 3;                                               // index within the role
@@ -134,7 +155,6 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     if (tid == 0) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
-    const int z = blockIdx.y;
     const int ntx = cdiv(a.W, PTW), nty = cdiv(a.H, PTH);
     const int total = a.N * ntx * nty;
     const int WSs = pm_ws(a.Ws), WSd = pm_ws(a.Wd);           // source / destination images may be larger than the view
@@ -143,20 +163,30 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     // bias of this z as fp32 in LDS: the accumulators of every tile start from it (32 fewer live registers
     // than carrying it, which is what lets two waves share a SIMD)
     // (slot r = the channel MFMA row r of the 64 computes: paired-block order, see the epilogue)
-    if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = a.bias ? a.bias[(long long)z * a.bias_zstride + pm_acc_chan(tid >> 4, tid & 15)] : 0.f;
+    if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = a.bias ? GP(const float, a.bias)[(long long)z * a.bias_zstride + pm_acc_chan(tid >> 4, tid & 15)] : 0.f;
 
     // ---- weights of this z: global [tap][cout][cin] -> LDS, row r = MFMA row (block r >> 4, row r & 15) holds output channel
     // pm_acc_chan(r >> 4, r & 15); chunk c of row r at (r*8 + (c ^ ((r>>1)&7))): the 16 rows a ds_read_b128 pass touches (same
     // chunk, rows 16 mb .. 16 mb + 15) then fall on 16 distinct 16-byte bank groups ----
-    auto stage_weights = [&]() {
-        const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.wpack) + (long long)z * a.w_zstride);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int idx = tid + i * PNT;                 // 4608 chunks
-            const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;
-            *reinterpret_cast<uint4*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wg[(tap * 64 + pm_acc_chan(r >> 4, r & 15)) * 8 + c];
-        }
-    };
+    // The four MFMA waves stage all 4608 chunks (18 per thread; the loads are issued first, the waves' own set-up arithmetic runs
+    // under their latency, then the LDS writes); the producer waves meanwhile do nothing but get the first tile's DMA out: at
+    // the start of a launch the tile is the critical path (r03 stamps: the producers took 2.7 k cycles of set-up + 2.2 k of
+    // issue + 3.2 k for their half of the weights before the first barrier; 8.4 k cycles of a 63 k-cycle launch).
+    constexpr int WCH = 9 * 64 * 8 / 256;                  // 18
+    const auto* wg = GP(const u32x4_t, a.wpack + (unsigned long long)((long long)z * a.w_zstride) * 2);
+    // (written out in the MFMA branch: a register array handed to a lambda by reference goes through scratch memory)
+#define W_LOAD(wv)                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
+        const int idx = tid + i * 256;                                                                                   \
+        const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
+        wv[i] = wg[(tap * 64 + pm_acc_chan(r >> 4, r & 15)) * 8 + c];                                                    \
+    }
+#define W_STORE(wv)                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
+        const int idx = tid + i * 256;                                                                                   \
+        const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
+        *reinterpret_cast<u32x4_t*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wv[i];                     \
+    }
 
     if (role == 1) {
         // =================== producer waves: LDS-DMA of the haloed tiles, one tile ahead ===================
@@ -166,8 +196,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         // tx) from the tile origin in the blocked layout (tx0 is a multiple of 32: the 32 inner pixels of a row are one
         // global segment, i.e. 512 contiguous bytes per chunk; the halo columns are the last / first pixel of the
         // neighbouring segments).
-        const char* src = reinterpret_cast<const char*>(a.src[0]);
-        const char* zsrc = reinterpret_cast<const char*>(g_conv_zero_chunk);
+        const auto* src = GP(const char, a.src0);
+        const auto* zsrc = GP(const char, g_conv_zero_chunk);
         int rel[NPIECE_W];
 #pragma unroll
         for (int i = 0; i < NPIECE_W; ++i) {
@@ -176,13 +206,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             const int c = rem / PTWH, tx = rem - c * PTWH;
             // view pixel (ty-1, tx-1) is source pixel (v*in_step + src_o): in_step 2 = one pixel-shuffle phase of a
             // twice-as-large tensor (the data gradient of conv3x3 + PixelShuffle, one launch per phase)
-            const int dx = (tx - 1) * a.in_step + a.src_ox[0];
-            rel[i] = (((((ty - 1) * a.in_step + a.src_oy[0]) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+            const int dx = (tx - 1) * a.in_step + a.src_ox0;
+            rel[i] = (((((ty - 1) * a.in_step + a.src_oy0) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
         }
         auto issue = [&](int tile, int buf) {
             int n, ty0, tx0;
             tile_coords(tile, ntx, nty, n, ty0, tx0);
-            const char* org = src + ((long long)n * a.src_nstride[0] + pm_off(ty0 * a.in_step, tx0 * a.in_step, 0, a.Ws, 64)) * 2;
+            const auto* org = src + ((long long)n * a.src_nstride0 + pm_off(ty0 * a.in_step, tx0 * a.in_step, 0, a.Ws, 64)) * 2;
             char* dstb = lds_t + buf * IN_BYTES;
             if (ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W) {          // interior tile (wave-uniform)
 #pragma unroll
@@ -198,17 +228,21 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
                     const int tx = rem % PTWH;
                     const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
-                    const char* s = (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) ? org + rel[i] : zsrc;
+                    const auto* s = (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) ? org + rel[i] : zsrc;
                     if (piece < NPIECE_T && idx < IN_CHUNKS) GLDS16(s, dstb + piece * 1024);
                 }
             }
         };
         int cur = 0;
         int tile = walk.first;
-        if (tile < walk.end) issue(tile, 0);               // first tile in flight while the weights are staged
-        stage_weights();
+        STAMP(q0);
+        if (tile < walk.end) issue(tile, 0);               // first tile in flight while the MFMA waves stage the weights
+        STAMP(q1);
+        STAMP_ADD(1, st_begin, q0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(q3);
         __syncthreads();                                   // weights and the first tile are in LDS
+        STAMP_ADD(2, st_begin, q1); STAMP_ADD(4, q1, q3);
         for (; tile < walk.end; tile += walk.stride) {
             STAMP(t0);
             const int next = tile + walk.stride;
@@ -229,6 +263,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         // Operand lane l = (i = l & 15, q = l >> 4): A[cout 16 mb + i][8 channels 8q..8q+7], B[same 8 channels][pixel i].
         // Fragment addresses: A two lane bases per channel half (taps 0-5 / 6-8: the immediate is 16 bits) + immediates
         // (tap, mb); B ONE lane base + immediates (row, ky, kx, half, channel half) of the [row][chunk][34 px][16 B] image.
+        STAMP(m0);
+        u32x4_t wv[WCH];
+        W_LOAD(wv)
         unsigned a_lo[2], a_hi[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -242,12 +279,22 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         int loff[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int dx = ((nb & 1) * 16 + pxl) * a.out_step + a.out_ox[z];
+            const int dx = ((nb & 1) * 16 + pxl) * a.out_step + a.out_oxz;
             loff[nb] = ((((w4 * 2 + (nb >> 1)) * a.out_step) * WSd + (dx >> 5)) * 8 + q) * 256 + (dx & 31) * 8;
         }
-        stage_weights();
+        W_STORE(wv)
+        STAMP(m1);
+        STAMP_ADD(6, m0, m1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // weights and the first tile are in LDS
+#ifdef VSR_STAMPS
+        st_sum[5] = stamp() - st_begin;                    // prologue of the MFMA waves (weights staged, first tile landed)
+#endif
+        auto* const dst_z = GP(bf16_t, a.dstz);
+        const auto* const res_z = GP(const bf16_t, a.resz);
+        const auto* const aux_z = GP(const bf16_t, a.auxz);
+        const auto* const sbits_z = GP(const u32x2_t, a.sign_bitsz);
+        auto* const sout_z = GP(u32x2_t, a.sign_outz);
         const float slope = vsr_slope(a.leaky_slope);      // LeakyReLU slope (0.1 on the BasicVSR path, 0.2 in the discriminator)
 
         int cur = 0;
@@ -256,13 +303,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             // epilogue operands, requested now, used after the K loop
             int n, ty0, tx0;
             tile_coords(tile, ntx, nty, n, ty0, tx0);
-            const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oy[z], tx0 * a.out_step, 0, a.Wd, 64);
+            const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oyz, tx0 * a.out_step, 0, a.Wd, 64);
             bool ok[4];
             constexpr bool BITS = MASK == MASK_RELU_BITS || MASK == MASK_LEAKY_BITS;
             constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE && !BITS;   // both bf16 operands early would not fit 2 waves / SIMD
-            uint4 rr[2][4], mm[2][4];                                // [k][nb]: 8 channels of one pixel
-            uint2 sbits = make_uint2(0u, 0u);                         // 64 sign bits of this lane's 64 outputs of the tile
-            if (BITS) sbits = reinterpret_cast<const uint2*>(a.sign_bits[z])[(long long)tile * 256 + w4 * 64 + lane];
+            u32x4_t rr[2][4], mm[2][4];                                // [k][nb]: 8 channels of one pixel
+            u32x2_t sbits = {0u, 0u};                         // 64 sign bits of this lane's 64 outputs of the tile
+            if (BITS) sbits = sbits_z[(long long)tile * 256 + w4 * 64 + lane];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 ok[nb] = (tx0 + (nb & 1) * 16 + pxl < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H);
@@ -270,8 +317,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const long long o = tbase + loff[nb] + k * 1024;
-                        if (HAS_RES) rr[k][nb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.res[z]) + o);
-                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[k][nb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + o);
+                        if (HAS_RES) rr[k][nb] = *GP(const u32x4_t, res_z + o);
+                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[k][nb] = *GP(const u32x4_t, aux_z + o);
                     }
                 }
             }
@@ -353,7 +400,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 if (ok[nb]) {
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(a.dst[z]) + tbase + loff[nb];
+                    auto* dst = dst_z + tbase + loff[nb];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         float v[8];
@@ -395,8 +442,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                                 for (int j = 0; j < 8; ++j) v[j] *= ((wbits >> (4 * nb + (j >> 1) + 16 * (j & 1))) & 1u) ? 1.f : neg;
                             } else if (MASK != MASK_NONE) {
                                 const float neg = MASK == MASK_LEAKY ? slope : 0.f;
-                                const uint4 mq = LATE_MASK ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux[z]) + tbase + loff[nb] + k * 1024)
-                                                           : mm[k][nb];
+                                u32x4_t mq = mm[k][nb];
+                                if (LATE_MASK) mq = *GP(const u32x4_t, aux_z + tbase + loff[nb] + k * 1024);
                                 const unsigned mw[4] = {mq.x, mq.y, mq.z, mq.w};
 #pragma unroll
                                 for (int jj = 0; jj < 4; ++jj) {
@@ -407,14 +454,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) ow[jj] = pk_bf16(v[2 * jj], v[2 * jj + 1]);
                         }
-                        const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                        if (!ABL(5)) *reinterpret_cast<uint4*>(dst + k * 1024) = o;
+                        const u32x4_t o = {ow[0], ow[1], ow[2], ow[3]};
+                        if (!ABL(5)) *GP(u32x4_t, dst + k * 1024) = o;
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
             }
-            if (ACT != ACT_NONE && !HAS_RES && a.sign_out[z] && !ABL(1))
-                reinterpret_cast<uint2*>(a.sign_out[z])[(long long)tile * 256 + w4 * 64 + lane] = make_uint2(sout[0], sout[1]);
+            if (ACT != ACT_NONE && !HAS_RES && sout_z && !ABL(1)) sout_z[(long long)tile * 256 + w4 * 64 + lane] = u32x2_t{sout[0], sout[1]};
             STAMP(t3);
             __syncthreads();                               // the producers' next tile has landed; everybody has finished reading `cur`
             cur ^= 1;
