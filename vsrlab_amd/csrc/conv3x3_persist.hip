@@ -32,6 +32,7 @@
 //     ReLU and the sign bits are computed on the PACKED bf16 words (v_pk_max_i16, v_pk_min_u16, v_lshl_or_b32: 1.5
 //     instructions per element instead of 4).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -92,6 +93,24 @@ __device__ __forceinline__ void tile_coords(int tile, int ntx, int nty, int& n, 
     ty0 = ty * PTH;
     tx0 = (r - ty * ntx) * PTW;
 }
+
+// Walks a workgroup's tiles first, first + stride, ... keeping (image, tile row, tile column): two divisions once, then a handful of
+// scalar adds and compares per tile (tile_coords per tile = two runtime divisions through v_rcp_iflag_f32, ~60 instructions).
+struct TileIter {
+    int tile, n, ty, tx;          // tile index; image, tile row, tile column
+    int sn, sty, stx;             // the stride in those units
+    __device__ __forceinline__ void init(int first, int stride, int ntx, int nty) {
+        const int per = ntx * nty;
+        tile = first; n = first / per; int r = first - n * per; ty = r / ntx; tx = r - ty * ntx;
+        sn = stride / per; r = stride - sn * per; sty = r / ntx; stx = r - sty * ntx;
+    }
+    __device__ __forceinline__ void advance(int stride, int ntx, int nty) {
+        tile += stride;
+        tx += stx; if (tx >= ntx) { tx -= ntx; ++ty; }
+        ty += sty; if (ty >= nty) { ty -= nty; ++n; }
+        n += sn;
+    }
+};
 
 // two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32), low half = a
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -209,9 +228,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             const int dx = (tx - 1) * a.in_step + a.src_ox0;
             rel[i] = (((((ty - 1) * a.in_step + a.src_oy0) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
         }
-        auto issue = [&](int tile, int buf) {
-            int n, ty0, tx0;
-            tile_coords(tile, ntx, nty, n, ty0, tx0);
+        auto issue = [&](const TileIter& it, int buf) {
+            const int n = it.n, ty0 = it.ty * PTH, tx0 = it.tx * PTW;
             const auto* org = src + ((long long)n * a.src_nstride0 + pm_off(ty0 * a.in_step, tx0 * a.in_step, 0, a.Ws, 64)) * 2;
             char* dstb = lds_t + buf * IN_BYTES;
             if (ty0 >= 1 && ty0 + PTH < a.H && tx0 >= 1 && tx0 + PTW < a.W) {          // interior tile (wave-uniform)
@@ -234,19 +252,20 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             }
         };
         int cur = 0;
-        int tile = walk.first;
+        TileIter it;
+        it.init(walk.first, walk.stride, ntx, nty);
         STAMP(q0);
-        if (tile < walk.end) issue(tile, 0);               // first tile in flight while the MFMA waves stage the weights
+        if (it.tile < walk.end) issue(it, 0);              // first tile in flight while the MFMA waves stage the weights
         STAMP(q1);
         STAMP_ADD(1, st_begin, q0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(q3);
         __syncthreads();                                   // weights and the first tile are in LDS
         STAMP_ADD(2, st_begin, q1); STAMP_ADD(4, q1, q3);
-        for (; tile < walk.end; tile += walk.stride) {
+        while (it.tile < walk.end) {
             STAMP(t0);
-            const int next = tile + walk.stride;
-            if (next < walk.end && !ABL(3)) issue(next, cur ^ 1);
+            it.advance(walk.stride, ntx, nty);
+            if (it.tile < walk.end && !ABL(3)) issue(it, cur ^ 1);
             STAMP(p1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP(p2);
@@ -297,13 +316,22 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         auto* const sout_z = GP(u32x2_t, a.sign_outz);
         const float slope = vsr_slope(a.leaky_slope);      // LeakyReLU slope (0.1 on the BasicVSR path, 0.2 in the discriminator)
 
+        // The bias of the wave's 16 rows per block (couts pm_acc_chan(mb, 4q + j)) stays in 16 registers and is the C operand of
+        // every accumulator's first MFMA: no per-tile initialisation (64 moves + 4 LDS reads per tile before).
+        f32x4_t bvec[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) bvec[mb] = *reinterpret_cast<const f32x4_t*>(smem + BIAS_OFF + (mb * 16 + 4 * q) * 4);
+
         int cur = 0;
-        for (int tile = walk.first; tile < walk.end; tile += walk.stride) {
+        TileIter it;
+        for (it.init(walk.first, walk.stride, ntx, nty); it.tile < walk.end; it.advance(walk.stride, ntx, nty)) {
             STAMP(t0);
             // epilogue operands, requested now, used after the K loop
-            int n, ty0, tx0;
-            tile_coords(tile, ntx, nty, n, ty0, tx0);
+            const int tile = it.tile, n = it.n, ty0 = it.ty * PTH, tx0 = it.tx * PTW;
             const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oyz, tx0 * a.out_step, 0, a.Wd, 64);
+            // a tile inside the image (all but the last tile row / column of a ragged size) needs no per-lane bounds: straight-line
+            // operand loads and epilogue (wave-uniform choice)
+            const bool full = ty0 + PTH <= a.H && tx0 + PTW <= a.W;
             bool ok[4];
             constexpr bool BITS = MASK == MASK_RELU_BITS || MASK == MASK_LEAKY_BITS;
             constexpr bool LATE_MASK = HAS_RES && MASK != MASK_NONE && !BITS;   // both bf16 operands early would not fit 2 waves / SIMD
@@ -311,26 +339,24 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             u32x2_t sbits = {0u, 0u};                         // 64 sign bits of this lane's 64 outputs of the tile
             if (BITS) sbits = sbits_z[(long long)tile * 256 + w4 * 64 + lane];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                ok[nb] = (tx0 + (nb & 1) * 16 + pxl < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H);
-                if (ok[nb]) {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const long long o = tbase + loff[nb] + k * 1024;
-                        if (HAS_RES) rr[k][nb] = *GP(const u32x4_t, res_z + o);
-                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[k][nb] = *GP(const u32x4_t, aux_z + o);
-                    }
-                }
+            for (int nb = 0; nb < 4; ++nb) ok[nb] = (tx0 + (nb & 1) * 16 + pxl < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H);
+#define CV_OPERANDS(OKN)                                                                                               \
+            _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) {                                                         \
+                if (OKN) {                                                                                             \
+                    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                    \
+                        const long long o = tbase + loff[nb] + k * 1024;                                               \
+                        if (HAS_RES) rr[k][nb] = *GP(const u32x4_t, res_z + o);                                        \
+                        if (MASK != MASK_NONE && !LATE_MASK && !BITS) mm[k][nb] = *GP(const u32x4_t, aux_z + o);       \
+                    }                                                                                                  \
+                }                                                                                                      \
             }
+            if (HAS_RES || (MASK != MASK_NONE && !LATE_MASK && !BITS)) {
+                if (full) { CV_OPERANDS(true) } else { CV_OPERANDS(ok[nb]) }
+            }
+#undef CV_OPERANDS
             STAMP(t1);
 
-            f32x4_t acc[4][4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {                        // accumulators start from the bias: couts 16 mb + 4 q + j
-                const float4 bv = *reinterpret_cast<const float4*>(smem + BIAS_OFF + (mb * 16 + 4 * q) * 4);
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) { acc[mb][nb][0] = bv.x; acc[mb][nb][1] = bv.y; acc[mb][nb][2] = bv.z; acc[mb][nb][3] = bv.w; }
-            }
+            f32x4_t acc[4][4];                                      // first written by step 0's MFMAs, whose C operand is the bias
 
             // ---- K loop: 18 steps s = (tap, channel half) of 16 MFMAs.  The 8 fragment reads of step s+1 are issued
             // before the MFMAs of step s, by hand: lgkmcnt(8) = "all but the 8 youngest LDS reads have returned" = step s
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                 CV_LOADA(tap_, kk_, slot, 0) CV_LOADA(tap_, kk_, slot, 1) CV_LOADA(tap_, kk_, slot, 2) CV_LOADA(tap_, kk_, slot, 3) \
                 CV_LOADB(ky_, kx_, kk_, slot, 0) CV_LOADB(ky_, kx_, kk_, slot, 1) CV_LOADB(ky_, kx_, kk_, slot, 2) CV_LOADB(ky_, kx_, kk_, slot, 3) \
             }
-#define CV_MFMA(s, mb, nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(s) % 2][mb], fb[(s) % 2][nb], acc[mb][nb], 0, 0, 0);
+#define CV_MFMA(s, mb, nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(s) % 2][mb], fb[(s) % 2][nb], (s) == 0 ? bvec[mb] : acc[mb][nb], 0, 0, 0);
             // one fragment read of step s+1 behind each of the first 8 MFMAs of step s: the wave's LDS issue slots sit in
             // the shadow of its own MFMAs, and the last read has 8 MFMAs (128 cycles) to return before step s+1 starts
 #define CV_ML_A(s, mb, nb, lmb)                                                                                        \
@@ -397,9 +423,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             // piece); word wd owns bits (wd & 15) [even channel] and 16 + (wd & 15) [odd channel] of sout[wd >> 4].
             unsigned sout[2] = {0u, 0u};
             const unsigned k11 = 0x00010001u;
+            auto epilogue = [&](auto FULL) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                if (ok[nb]) {
+                if (decltype(FULL)::value || ok[nb]) {
                     auto* dst = dst_z + tbase + loff[nb];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
@@ -460,6 +487,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                     }
                 }
             }
+            };
+            if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
             if (ACT != ACT_NONE && !HAS_RES && sout_z && !ABL(1)) sout_z[(long long)tile * 256 + w4 * 64 + lane] = u32x2_t{sout[0], sout[1]};
             STAMP(t3);
             __syncthreads();                               // the producers' next tile has landed; everybody has finished reading `cur`
