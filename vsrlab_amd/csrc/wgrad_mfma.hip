@@ -396,6 +396,14 @@ static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
 //     sets (48 registers) are live.  hipcc counts the lgkmcnt waits itself; sched_group_barrier pins the
 //     interleave "2 MFMAs, 2 reads".
 // ---------------------------------------------------------------------------------------------------
+// Diagnostic build only (make ABL=<bits> ABLSRC=wgrad_mfma): bit 0: the producers issue only the first tile's DMA (consumer-only
+// period); bit 1: the consumers skip the K loop (producer-only period).  Results are wrong by construction; only run time is read.
+// bit 2: B fragments are read for the ky = 0 groups only (what sharing an X row's fragments across ky would save in LDS reads).
+#ifdef VSR_ABL
+#define WABL(bit) ((VSR_ABL >> (bit)) & 1)
+#else
+#define WABL(bit) 0
+#endif
 __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -451,14 +459,35 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 if (tx >= TW) padmask |= 1u << i;
             }
         }
-        auto issue = [&](int T, int s) {
-            const int seg = T / per_seg;
-            const int r0 = T - seg * per_seg;
-            const int n = r0 / tiles_per_img;
-            const int r1 = r0 - n * tiles_per_img;
-            const int ty0 = (r1 / a.ntiles_x) * TH, tx0 = (r1 % a.ntiles_x) * TW;
-            const char* xb = reinterpret_cast<const char*>(a.x[seg]) + (long long)n * a.x_nstride * 2;
-            const char* yb = reinterpret_cast<const char*>(a.dy[seg]) + (long long)n * a.dy_nstride * 2;
+        // (segment, image, tile row, tile column) of the walk, advanced by adds and carries (four runtime divisions per tile
+        // before); a segment's base pointers are re-read from the kernel arguments only when the segment changes
+        struct { int T, seg, n, ty, tx, sseg, sn, sty, stx; } it;
+        {
+            int r = walk.first;
+            it.T = r; it.seg = r / per_seg; r -= it.seg * per_seg; it.n = r / tiles_per_img; r -= it.n * tiles_per_img;
+            it.ty = r / a.ntiles_x; it.tx = r - it.ty * a.ntiles_x;
+            r = walk.stride;
+            it.sseg = r / per_seg; r -= it.sseg * per_seg; it.sn = r / tiles_per_img; r -= it.sn * tiles_per_img;
+            it.sty = r / a.ntiles_x; it.stx = r - it.sty * a.ntiles_x;
+        }
+        auto advance = [&]() {
+            it.T += walk.stride;
+            it.tx += it.stx; if (it.tx >= a.ntiles_x) { it.tx -= a.ntiles_x; ++it.ty; }
+            it.ty += it.sty; if (it.ty >= a.ntiles_y) { it.ty -= a.ntiles_y; ++it.n; }
+            it.n += it.sn; if (it.n >= a.N) { it.n -= a.N; ++it.seg; }
+            it.seg += it.sseg;
+        };
+        int cseg = -1;
+        const char *xseg = nullptr, *yseg = nullptr;
+        auto issue = [&](int s) {
+            if (it.seg != cseg) {                                  // wave-uniform, a few times per launch
+                cseg = it.seg;
+                xseg = reinterpret_cast<const char*>(a.x[cseg]);
+                yseg = reinterpret_cast<const char*>(a.dy[cseg]);
+            }
+            const int ty0 = it.ty * TH, tx0 = it.tx * TW;
+            const char* xb = xseg + (long long)it.n * a.x_nstride * 2;
+            const char* yb = yseg + (long long)it.n * a.dy_nstride * 2;
             const char* xo = xb + pm_off(ty0 * a.x_step + x_oy, tx0 * a.x_step, x_coff, a.Wx, xcp * 8) * 2;      // tx0*step: multiple of 32
             const char* yo = yb + pm_off(ty0 * a.dy_step + a.dy_oy, tx0 * a.dy_step, dy_coff, a.Wy, ycp * 8) * 2;
             char* lxs = smem + s * DSET;
@@ -468,8 +497,9 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 const int piece = w4 + 4 * i;
                 const bool isx = piece < DX_PIECES;
                 const char* src = (isx ? xo : yo) + rel[i];
-                bool valid = !((padmask >> i) & 1u);
-                if (!interior && valid) {
+                const bool pad = (padmask >> i) & 1u;              // padding slots of the LDS images are never read: their lanes load nothing
+                bool valid = true;
+                if (!interior && !pad) {
                     if (isx) {
                         const int idx = piece * 64 + lane;
                         const int row = idx / (8 * XS), tx = (idx - row * (8 * XS)) % XS;
@@ -483,8 +513,8 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 }
                 if (!valid) src = zsrc;
                 char* dst = isx ? lxs + piece * 1024 : lxs + DXB + (piece - DX_PIECES) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                if (!pad) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
         };
         float bsum[8];
@@ -492,19 +522,25 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
         for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
         const int pt = tid - 256;                              // 0..255: chunk pt & 7, pixels (pt >> 3) + 32 i
         int cur = 0;
-        int T = walk.first;
-        if (T < walk.end) issue(T, 0);
+        if (it.T < walk.end) issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // the first tile is in LDS
-        for (; T < walk.end; T += walk.stride) {
-            const char* ly = smem + cur * DSET + DXB;
+        while (it.T < walk.end) {
+            // The next tile's DMA goes out FIRST: the stream of 80 KiB per tile is what bounds the producers (24 GB/s per CU,
+            // the chip's LDS-DMA rate), and anything in front of the issue delays the whole transfer.  The bias-gradient partial
+            // sums of the CURRENT dY tile follow, read by inline asm (hipcc would put a vmcnt(0) in front of a plain LDS read
+            // while LDS-DMA is in flight; the DMA writes the OTHER buffer set).
+            const unsigned lyb = (unsigned)(cur * DSET + DXB + (pt & 7) * (YS * 16) + (pt >> 3) * 16);
+            advance();
+            if (it.T < walk.end && !WABL(0)) issue(cur ^ 1);
+            uint4 bq[8];
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:%9\n\tds_read_b128 %2, %8 offset:%10\n\tds_read_b128 %3, %8 offset:%11\n\t"
+                         "ds_read_b128 %4, %8 offset:%12\n\tds_read_b128 %5, %8 offset:%13\n\tds_read_b128 %6, %8 offset:%14\n\tds_read_b128 %7, %8 offset:%15\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bq[4]), "=&v"(bq[5]), "=&v"(bq[6]), "=&v"(bq[7])
+                         : "v"(lyb), "i"(YROW), "i"(2 * YROW), "i"(3 * YROW), "i"(4 * YROW), "i"(5 * YROW), "i"(6 * YROW), "i"(7 * YROW) : "memory");
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {                      // bias-gradient partial sums of the current dY tile
-                const int p = (pt >> 3) + 32 * i;
-                chunk_sum(*reinterpret_cast<const uint4*>(ly + (p >> 5) * YROW + (pt & 7) * (YS * 16) + (p & 31) * 16), bsum);
-            }
-            const int next = T + walk.stride;
-            if (next < walk.end) issue(next, cur ^ 1);
+            for (int i = 0; i < 8; ++i) chunk_sum(bq[i], bsum);   // pixel (pt >> 3) of tile row i, chunk pt & 7
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                   // next tile landed; the consumers are done with `cur`
             cur ^= 1;
@@ -553,7 +589,8 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
             // group g = (row r, ky): fragment fi = (kx, cin half nb); two MFMAs (cout halves) per fragment, then the
             // fragment's register is re-requested for group g + 2 (12 reads per group while g + 2 < 24).  A of row r + 1:
             // one cout half (2 reads) in each of the groups ky = 0, 1.  Reads issued during group g:
-#define PC_ISSUED(g_) ((((g_) + 2 < 24) ? 12 : 0) + ((((g_) % 3) < 2 && (g_) / 3 + 1 < 8) ? 2 : 0))
+#define PC_BREAD(g_) ((g_) + 2 < 24 && !(WABL(2) && ((g_) + 2) % 3 != 0))      /* ablation bit 2: only the ky = 0 groups' B fragments are read */
+#define PC_ISSUED(g_) ((PC_BREAD(g_) ? 12 : 0) + ((((g_) % 3) < 2 && (g_) / 3 + 1 < 8) ? 2 : 0))
             // At the top of group g everything older than group g-1's requests must be back (g = 0: the prologue's B(1)).
 #define PC_FRAG(g_, fi_)                                                                                                   \
             {                                                                                                              \
@@ -562,17 +599,20 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 acc[t_][0][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r_ & 1][0].b, B[(g_) & 1][fi_].b, acc[t_][0][nb_], 0, 0, 0); \
                 acc[t_][1][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r_ & 1][1].b, B[(g_) & 1][fi_].b, acc[t_][1][nb_], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                                         \
-                if ((g_) + 2 < 24) PC_LDB((g_) + 2, fi_, B[(g_) & 1][fi_])                                                 \
+                if (PC_BREAD(g_)) PC_LDB((g_) + 2, fi_, B[(g_) & 1][fi_])                                                  \
                 if ((fi_) == 0 && ky_ < 2 && r_ + 1 < 8) PC_LDA(r_ + 1, ky_, A[(r_ + 1) & 1][ky_])                         \
                 __builtin_amdgcn_sched_barrier(0);                                                                         \
             }
 #define PC_GROUP(g_) PC_FRAG(g_, 0) PC_FRAG(g_, 1) PC_FRAG(g_, 2) PC_FRAG(g_, 3) PC_FRAG(g_, 4) PC_FRAG(g_, 5)
+            if (!WABL(1)) {
             PC_GROUP(0) PC_GROUP(1) PC_GROUP(2) PC_GROUP(3) PC_GROUP(4) PC_GROUP(5) PC_GROUP(6) PC_GROUP(7)
             PC_GROUP(8) PC_GROUP(9) PC_GROUP(10) PC_GROUP(11) PC_GROUP(12) PC_GROUP(13) PC_GROUP(14) PC_GROUP(15)
             PC_GROUP(16) PC_GROUP(17) PC_GROUP(18) PC_GROUP(19) PC_GROUP(20) PC_GROUP(21) PC_GROUP(22) PC_GROUP(23)
+            }
 #undef PC_GROUP
 #undef PC_FRAG
 #undef PC_ISSUED
+#undef PC_BREAD
 #undef PC_WAIT
 #undef PC_LDB
 #undef PC_LDA
