@@ -38,6 +38,8 @@ def main():
         launch(libs[i % len(libs)], i)
     torch.cuda.synchronize()
     res = {n: [] for n in names}
+    clk = {}
+    extra = {}
     for r in range(rounds):
         for n, lib in zip(names, libs):
             for i in range(nsets):
@@ -48,9 +50,17 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             res[n].append(e0.elapsed_time(e1) / iters * 1e3)
+            if hasattr(lib, "vsr_debug_read_wclk"):
+                out = np.zeros(1024, dtype=np.uint64)
+                if lib.vsr_debug_read_wclk(out.ctypes.data_as(P)) == 0:
+                    o = out.reshape(256, 4).astype(np.float64)
+                    ok = o[:, 1] > 0
+                    clk.setdefault(n, []).append(float(np.median(o[ok, 0] / o[ok, 1] * 0.1)))
+                    extra[n] = (float(np.median(o[ok, 0])), float(np.median(o[ok, 2])), float(np.median(o[ok, 3])))
     for n in names:
         a = np.array(res[n])
-        print(f"{n:40s} 7-frame wgrad + reduce: med {np.median(a):7.1f} min {a.min():7.1f} us  ({np.median(a) / nf:.1f} us per frame-conv)", flush=True)
+        print(f"{n:40s} 7-frame wgrad + reduce: med {np.median(a):7.1f} min {a.min():7.1f} us  ({np.median(a) / nf:.1f} us per frame-conv)"
+              + (f"  in-kernel clock {np.median(clk[n]):.3f} GHz; per workgroup {extra[n][0] / 1e3:.1f} k cycles, {extra[n][2]:.0f} tiles, consumer barrier wait {extra[n][1] / 1e3:.1f} k cycles" if n in clk else ""), flush=True)
 
 
 if __name__ == "__main__":

@@ -398,9 +398,11 @@ static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
 // ---------------------------------------------------------------------------------------------------
 // Diagnostic build only (make ABL=<bits> ABLSRC=wgrad_mfma): bit 0: the producers issue only the first tile's DMA (consumer-only
 // period); bit 1: the consumers skip the K loop (producer-only period).  Results are wrong by construction; only run time is read.
-// bit 2: B fragments are read for the ky = 0 groups only (what sharing an X row's fragments across ky would save in LDS reads).
+// (r03: "B fragments for the ky = 0 groups only" measured -4 % with the DMA on, -7 % without: the K loop now shares an X row's
+// fragments across ky.)
 #ifdef VSR_ABL
 #define WABL(bit) ((VSR_ABL >> (bit)) & 1)
+__device__ unsigned long long g_wclk[256 * 4];          // [workgroup][cycles, 100 MHz ticks, consumer barrier-wait cycles, tiles] of the last launch
 #else
 #define WABL(bit) 0
 #endif
@@ -409,6 +411,10 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2);            // 0: MFMA consumer, 1: LDS-DMA producer
     const int w4 = __builtin_amdgcn_readfirstlane(wave & 3);
+#ifdef VSR_ABL
+    unsigned long long clk_t0 = 0, clk_r0 = 0, clk_bar = 0, clk_tiles = 0;
+    if (tid == 0) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     const int tiles_per_img = a.ntiles_x * a.ntiles_y;
     const int per_seg = a.N * tiles_per_img;
     const int total = a.nseg * per_seg;
@@ -572,52 +578,65 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
         for (int T = walk.first; T < walk.end; T += walk.stride) {
             const unsigned lx = (unsigned)(cur * DSET + xoff);  // LDS byte addresses (the dynamic segment starts at 0)
             const unsigned ly = (unsigned)(cur * DSET + yoff);
-            frag_u A[2][2], B[2][6];
-            // Fragment reads are inline asm (hipcc sinks builtin LDS reads back in front of their consumers: with the
-            // builtin the lookahead collapsed to 1-3 fragments), so the waits are counted here.  LDS operations return in
-            // order: lgkmcnt(N) = "all but the N youngest reads of this wave have returned".
+            // The K loop walks the tile's 10 haloed X rows R: the six B fragments of row R (kx x cin half) serve the groups
+            // (ky, r = R - ky) of up to three output rows, so an X row is read from LDS once instead of three times (r03: 160
+            // instead of 320 transposing reads per tile and wave; a read costs the wave ~4 issue cycles that the MFMA cadence does
+            // not hide: 5.9 k -> 5.3 k cycles per tile).  A fragments (dY rows r) live in three slots r % 3 for the three steps
+            // that use them.  Reads of step R + 1 are issued behind the MFMA pairs of step R (inline asm: hipcc sinks builtin
+            // LDS reads back in front of their consumers); LDS operations return in order, and at the top of a step everything
+            // issued during the previous one is needed: lgkmcnt(0).
+            frag_u A[3][2], B[2][6];
 #define PC_TRR(dst_, addr_, imm_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(imm_))
 #define PC_LDA(r_, mb_, f_) { PC_TRR((f_).s[0], ly, (r_) * YROW + (mb_) * (2 * YS * 16)); PC_TRR((f_).s[1], ly, (r_) * YROW + (mb_) * (2 * YS * 16) + 64); }
-#define PC_LDB(g_, fi_, f_) { PC_TRR((f_).s[0], lx, ((g_) / 3 + (g_) % 3) * XROW + ((fi_) & 1) * (2 * XS * 16) + ((fi_) >> 1) * 16);      \
-                              PC_TRR((f_).s[1], lx, ((g_) / 3 + (g_) % 3) * XROW + ((fi_) & 1) * (2 * XS * 16) + ((fi_) >> 1) * 16 + 64); }
-#define PC_WAIT(n_) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(n_) : "memory")
+#define PC_LDB(R_, fi_, f_) { PC_TRR((f_).s[0], lx, (R_) * XROW + ((fi_) & 1) * (2 * XS * 16) + ((fi_) >> 1) * 16);      \
+                              PC_TRR((f_).s[1], lx, (R_) * XROW + ((fi_) & 1) * (2 * XS * 16) + ((fi_) >> 1) * 16 + 64); }
             __builtin_amdgcn_sched_barrier(0);
             PC_LDA(0, 0, A[0][0]) PC_LDA(0, 1, A[0][1])
             PC_LDB(0, 0, B[0][0]) PC_LDB(0, 1, B[0][1]) PC_LDB(0, 2, B[0][2]) PC_LDB(0, 3, B[0][3]) PC_LDB(0, 4, B[0][4]) PC_LDB(0, 5, B[0][5])
-            PC_LDB(1, 0, B[1][0]) PC_LDB(1, 1, B[1][1]) PC_LDB(1, 2, B[1][2]) PC_LDB(1, 3, B[1][3]) PC_LDB(1, 4, B[1][4]) PC_LDB(1, 5, B[1][5])
             __builtin_amdgcn_sched_barrier(0);
-            // group g = (row r, ky): fragment fi = (kx, cin half nb); two MFMAs (cout halves) per fragment, then the
-            // fragment's register is re-requested for group g + 2 (12 reads per group while g + 2 < 24).  A of row r + 1:
-            // one cout half (2 reads) in each of the groups ky = 0, 1.  Reads issued during group g:
-#define PC_BREAD(g_) ((g_) + 2 < 24 && !(WABL(2) && ((g_) + 2) % 3 != 0))      /* ablation bit 2: only the ky = 0 groups' B fragments are read */
-#define PC_ISSUED(g_) ((PC_BREAD(g_) ? 12 : 0) + ((((g_) % 3) < 2 && (g_) / 3 + 1 < 8) ? 2 : 0))
-            // At the top of group g everything older than group g-1's requests must be back (g = 0: the prologue's B(1)).
-#define PC_FRAG(g_, fi_)                                                                                                   \
+            // pair P of step R = (ky, fragment fi): two MFMAs (cout halves), then the reads scheduled behind it: B[R+1][P] for
+            // P < 6; A[R+1] (slot (R+1) % 3 = the slot of row R-2, free once the ky = 2 group -- the first six pairs -- is
+            // done) behind pairs 6 and 7, or behind pairs 4 and 5 of the one-group step R = 0.
+#define PC_PAIR(R_, ky_, fi_, P_, NV_)                                                                                     \
             {                                                                                                              \
-                constexpr int r_ = (g_) / 3, ky_ = (g_) % 3, kx_ = (fi_) >> 1, nb_ = (fi_) & 1, t_ = ky_ * 3 + kx_;        \
-                if ((fi_) == 0) { PC_WAIT((g_) == 0 ? 12 : PC_ISSUED((g_) - 1)); __builtin_amdgcn_sched_barrier(0); }     \
-                acc[t_][0][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r_ & 1][0].b, B[(g_) & 1][fi_].b, acc[t_][0][nb_], 0, 0, 0); \
-                acc[t_][1][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r_ & 1][1].b, B[(g_) & 1][fi_].b, acc[t_][1][nb_], 0, 0, 0); \
+                constexpr int r_ = (R_) - (ky_), t_ = (ky_) * 3 + ((fi_) >> 1), nb_ = (fi_) & 1;                           \
+                acc[t_][0][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r_ % 3][0].b, B[(R_) & 1][fi_].b, acc[t_][0][nb_], 0, 0, 0); \
+                acc[t_][1][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r_ % 3][1].b, B[(R_) & 1][fi_].b, acc[t_][1][nb_], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                                         \
-                if (PC_BREAD(g_)) PC_LDB((g_) + 2, fi_, B[(g_) & 1][fi_])                                                  \
-                if ((fi_) == 0 && ky_ < 2 && r_ + 1 < 8) PC_LDA(r_ + 1, ky_, A[(r_ + 1) & 1][ky_])                         \
+                if ((P_) < 6 && (R_) + 1 <= 9) PC_LDB((R_) + 1, P_, B[((R_) + 1) & 1][P_])                                 \
+                if ((R_) + 1 <= 7 && (P_) == ((NV_) >= 2 ? 6 : 4)) PC_LDA((R_) + 1, 0, A[((R_) + 1) % 3][0])                \
+                if ((R_) + 1 <= 7 && (P_) == ((NV_) >= 2 ? 7 : 5)) PC_LDA((R_) + 1, 1, A[((R_) + 1) % 3][1])                \
                 __builtin_amdgcn_sched_barrier(0);                                                                         \
             }
-#define PC_GROUP(g_) PC_FRAG(g_, 0) PC_FRAG(g_, 1) PC_FRAG(g_, 2) PC_FRAG(g_, 3) PC_FRAG(g_, 4) PC_FRAG(g_, 5)
+#define PC_GRP(R_, ky_, P0_, NV_) PC_PAIR(R_, ky_, 0, (P0_), NV_) PC_PAIR(R_, ky_, 1, (P0_) + 1, NV_) PC_PAIR(R_, ky_, 2, (P0_) + 2, NV_) \
+                                  PC_PAIR(R_, ky_, 3, (P0_) + 3, NV_) PC_PAIR(R_, ky_, 4, (P0_) + 4, NV_) PC_PAIR(R_, ky_, 5, (P0_) + 5, NV_)
+#define PC_TOP { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
             if (!WABL(1)) {
-            PC_GROUP(0) PC_GROUP(1) PC_GROUP(2) PC_GROUP(3) PC_GROUP(4) PC_GROUP(5) PC_GROUP(6) PC_GROUP(7)
-            PC_GROUP(8) PC_GROUP(9) PC_GROUP(10) PC_GROUP(11) PC_GROUP(12) PC_GROUP(13) PC_GROUP(14) PC_GROUP(15)
-            PC_GROUP(16) PC_GROUP(17) PC_GROUP(18) PC_GROUP(19) PC_GROUP(20) PC_GROUP(21) PC_GROUP(22) PC_GROUP(23)
+            PC_TOP PC_GRP(0, 0, 0, 1)                                                     // R = 0: output row 0
+            PC_TOP PC_GRP(1, 1, 0, 2) PC_GRP(1, 0, 6, 2)                                  // R = 1: rows 0 (ky 1), 1 (ky 0)
+            PC_TOP PC_GRP(2, 2, 0, 3) PC_GRP(2, 1, 6, 3) PC_GRP(2, 0, 12, 3)
+            PC_TOP PC_GRP(3, 2, 0, 3) PC_GRP(3, 1, 6, 3) PC_GRP(3, 0, 12, 3)
+            PC_TOP PC_GRP(4, 2, 0, 3) PC_GRP(4, 1, 6, 3) PC_GRP(4, 0, 12, 3)
+            PC_TOP PC_GRP(5, 2, 0, 3) PC_GRP(5, 1, 6, 3) PC_GRP(5, 0, 12, 3)
+            PC_TOP PC_GRP(6, 2, 0, 3) PC_GRP(6, 1, 6, 3) PC_GRP(6, 0, 12, 3)
+            PC_TOP PC_GRP(7, 2, 0, 3) PC_GRP(7, 1, 6, 3) PC_GRP(7, 0, 12, 3)
+            PC_TOP PC_GRP(8, 2, 0, 2) PC_GRP(8, 1, 6, 2)                                  // R = 8: rows 6 (ky 2), 7 (ky 1)
+            PC_TOP PC_GRP(9, 2, 0, 1)                                                     // R = 9: row 7
             }
-#undef PC_GROUP
-#undef PC_FRAG
-#undef PC_ISSUED
-#undef PC_BREAD
-#undef PC_WAIT
+#undef PC_TOP
+#undef PC_GRP
+#undef PC_PAIR
 #undef PC_LDB
 #undef PC_LDA
 #undef PC_TRR
+#ifdef VSR_ABL
+            unsigned long long b0; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b0) :: "memory");
+#endif
             __syncthreads();                                   // next tile landed; everybody is done with `cur`
+#ifdef VSR_ABL
+            unsigned long long b1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b1) :: "memory");
+            clk_bar += b1 - b0; ++clk_tiles;
+#endif
             cur ^= 1;
         }
         // ---- ONE partial slab per workgroup: [tap][64 cout][64 cin].  Accumulator (tap, mb, nb), register j =
@@ -641,6 +660,14 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
             slab[9 * 64 * 64 + tid] = s;
         }
     }
+#ifdef VSR_ABL
+    if (tid == 0 && blockIdx.x < 256) {
+        g_wclk[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_wclk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        g_wclk[blockIdx.x * 4 + 2] = clk_bar;
+        g_wclk[blockIdx.x * 4 + 3] = clk_tiles;
+    }
+#endif
 }
 
 int launch_wgrad_pc(const WgradArgs& a0, int nwg, hipStream_t st) {      // nwg workgroups = nwg slabs
@@ -656,6 +683,13 @@ int launch_wgrad_pc(const WgradArgs& a0, int nwg, hipStream_t st) {      // nwg 
 }
 
 }  // namespace
+
+#ifdef VSR_ABL
+extern "C" int vsr_debug_read_wclk(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wclk), sizeof(unsigned long long) * 256 * 4) == hipSuccess ? 0 : -3;
+}
+#endif
+
 
 
 #define VSR_WGRAD_SHAPES(X)           \
