@@ -28,6 +28,26 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
+PROFILE_JSON = os.path.join("profiles", "r03_roofline.json")     # committed rocprofv3 summary of THIS command (profiles/README.md)
+
+
+def tree_id():
+    """What produced the binary that is running: sha1 over the kernel sources (vsrlab_amd/csrc, include) as they lie in this tree,
+    plus the git HEAD that `build()` recorded next to the library (the GPU box has no .git).  profiles/summarize.py stamps the
+    same sha1 into the committed profile summary, so replayed counters can be tied to -- or dropped for -- the running code."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vsrlab_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vsrlab_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    out = {"csrc_sha1": h.hexdigest()[:16]}
+    try:
+        out.update(json.load(open(os.path.join(ROOT, "vsrlab_amd", "lib", "BUILD_INFO.json"))))
+    except Exception:
+        pass
+    return out
 
 
 def algorithmic_bytes_per_frame(h, w, t, rb, es=2):
@@ -126,15 +146,22 @@ def dominant_kernel_roofline(dev, h, w, iters=48, nsets=8):
            "traffic": None, "kernel": "conv3x3_c64_persist_kernel<ACT,RES,MASK> (bias+ReLU / bias+skip alternating, 8 rotating 66 MB buffer sets)",
            "avg_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bytes, "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
-    # From committed rocprofv3 runs of THIS command (profiles/README.md): HBM bytes per launch from the PMC passes
-    # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section), the MFMA-busy counters, and the same kernel's
-    # call-weighted figure inside one timed step of the single-stream kernel trace.
+    # Everything above was measured in THIS process.  The PMC counters cannot be (rocprofv3 passes are separate runs): they are
+    # replayed from the committed summary of the same command, under their own key and ONLY when that summary was produced from
+    # the kernel sources that are running now; `traffic` stays null otherwise.
+    tid = tree_id()
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline.json")))
-        out["traffic"] = pj.get("hbm_bytes_per_launch")
-        for k in ("in_step", "mfma_busy"):
-            if k in pj:
-                out[k] = pj[k]
+        pj = json.load(open(os.path.join(ROOT, PROFILE_JSON)))
+        src = {"file": PROFILE_JSON, "csrc_sha1": pj.get("csrc_sha1"), "git_head": pj.get("git_head"),
+               "measured_on": "the builder's gpurun box under rocprofv3, not in this run"}
+        if pj.get("csrc_sha1") == tid["csrc_sha1"]:
+            out["traffic"] = pj.get("hbm_bytes_per_launch")
+            for k in ("in_step", "mfma_busy", "in_kernel_clock_GHz", "roofline_leg_avg_us_rocprof"):
+                if k in pj:
+                    src[k] = pj[k]
+        else:
+            src["stale"] = "kernel sources differ from the profiled ones: counters not replayed"
+        out["counters_from"] = src
     except Exception:
         pass
     return out
@@ -216,7 +243,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.roofline_only:
-        print(json.dumps(dominant_kernel_roofline(dev, args.height, args.width)), flush=True)
+        leg = dominant_kernel_roofline(dev, args.height, args.width)
+        leg["tree"] = tree_id()
+        print(json.dumps(leg), flush=True)
         return
     dist = None
     use_dist = world > 1 or "RANK" in os.environ     # under torchrun even a 1-rank job takes the DDP / RCCL path
@@ -240,7 +269,7 @@ def main():
         opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0)
         if use_dist:
             from vsrlab_amd.parallel import FlatGradSync
-            sync = FlatGradSync(opt.flat_grads, params=opt.flat_params)    # start-up broadcast + one all-reduce per step
+            sync = FlatGradSync(opt.flat_grads, params=opt.flat_params, optimizer=opt)    # start-up broadcast + one all-reduce per step
     else:
         if use_dist:
             from torch.nn.parallel import DistributedDataParallel
@@ -299,7 +328,7 @@ def main():
                        "parallelism": (f"dp{world} (clip-level; " + ("one RCCL all-reduce of the flat gradient arena per step)" if sync is not None
                                                                         else "DDP grad all-reduce over RCCL)")) if world > 1 else "single GPU",
                        "optimizer_in_timed_region": "fused clip_grad_norm(1)+Adam (HIP)" if args.optimizer == "fused" else "torch.optim.Adam"},
-            "loss": round(loss_val, 6),
+            "loss": round(loss_val, 6), "tree": tree_id(),
         }
         bpf = algorithmic_bytes_per_frame(h, w, t, args.res_blocks, 2 if args.dtype == "bf16" else 4)
         fpf = flops_per_frame(h, w, t, args.res_blocks)

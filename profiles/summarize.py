@@ -47,6 +47,25 @@ def main():
     shutil.copy(os.path.join(src, "trace2s", "bench_kernel_stats.csv"), os.path.join(here, f"{tag}_bench_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "trace1s", "bench_kernel_stats.csv"), os.path.join(here, f"{tag}_bench_kernel_stats_single_stream.csv"))
     out = {"_how": __doc__.split("Outputs:")[0].strip()}
+    # ---- which code was profiled: bench.py --roofline-only prints its tree id (sha1 of the kernel sources + the git HEAD build()
+    # recorded); bench.py replays the counters below only when the running tree has the same sha1 ----
+    for log in ("pmc_fetch.log", "pmc_write.log", "pmc_mfma.log"):
+        try:
+            for line in open(os.path.join(src, log)):
+                if line.startswith("{") and '"tree"' in line:
+                    tree = json.loads(line)["tree"]
+                    out["csrc_sha1"], out["git_head"] = tree.get("csrc_sha1"), tree.get("git_head")
+        except OSError:
+            pass
+    # ---- in-kernel clock of the dominant kernel: tools/ab_conv.py with the ABL=0 diagnostic build (s_memtime / s_memrealtime around
+    # the kernel, median over workgroups; MI355X_MICROARCH "DVFS give-back" item 6), same box and call as the traces ----
+    try:
+        import re
+        m = re.findall(r"clock ([0-9.]+) GHz", open(os.path.join(src, "clock.log")).read())
+        if m:
+            out["in_kernel_clock_GHz"] = float(m[-1])
+    except OSError:
+        pass
     # ---- roofline leg: its 48 timed launches are the last 48 persistent-conv rows of any trace of bench.py ----
     tr = [r for r in rows(os.path.join(src, "trace1s", "bench_kernel_trace.csv")) if KERN in r["Kernel_Name"]]
     tail = tr[-48:]
@@ -72,10 +91,12 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in mf:
             # busy cycles are summed over the chip's 1024 SIMDs.  GRBM_GUI_ACTIVE / 8 over-reads the clock on dispatches this
             # short (MI355X_MICROARCH, DVFS give-back), so the fraction is quoted against the in-kernel clock measured with
-            # s_memtime stamps (round 1, tools/stamps_conv.py: 1.55-1.6 GHz under this load) and the trace's duration.
+            # s_memtime / s_memrealtime stamps (clock.log above; 1.6 GHz if that log is missing) and the trace's duration.
             per_simd = mf["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
             mf["mfma_busy_cycles_per_simd"] = round(per_simd)
-            mf["mfma_busy_frac_at_1.6GHz"] = round(per_simd / (out["roofline_leg_avg_us_rocprof"] * 1600.0), 4)
+            ghz = out.get("in_kernel_clock_GHz", 1.6)
+            mf["mfma_busy_frac_at_in_kernel_clock"] = round(per_simd / (out["roofline_leg_avg_us_rocprof"] * 1000.0 * ghz), 4)
+            mf["clock_GHz_used"] = ghz
         out["mfma_busy"] = mf
     # ---- the same kernel inside ONE timed step (single-stream trace: no overlap inflating durations) ----
     # bench.py --steps 1 --warmup 1: the trace holds 2 steps, then the roofline leg (8 warm + 48 timed launches + 4 set-up)

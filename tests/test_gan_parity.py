@@ -276,3 +276,31 @@ def test_config3_full_size_gan_iteration():
               f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.0f} GiB")
     finally:
         del os_env["VSRLAB_AMD_DTYPE"]
+
+
+# ---- round-2 ADVICE: the GAN step functions open the reference's autocast regions (train_gan.py:38-42,52-56) ----
+@pytest.mark.gpu
+def test_gan_steps_open_the_references_autocast_regions():
+    _gpu()                                                 # torch disables a "cuda" autocast region on a box without a GPU
+    from vsrlab_amd import functional as VF
+    from vsrlab_amd import train_gan as TG
+    seen = []
+
+    def model(lr):                                         # stands for RealBasicVSR: records what its forward would resolve
+        seen.append(("model", VF.resolve_dtype()))
+        return torch.zeros(1, 2, 3, 8, 8, requires_grad=True), None
+
+    def disc(x):
+        seen.append(("disc", VF.resolve_dtype()))
+        return x.mean(dim=(1, 2, 3))
+
+    import os
+    os.environ.pop("VSRLAB_AMD_DTYPE", None)
+    assert VF.resolve_dtype() == VF.DT_F32                # outside the step functions nothing is overridden
+    hr = torch.zeros(1, 2, 3, 8, 8)
+    sr, loss, _, _ = TG.generator_step(model, disc, lambda a, b: (a - b).abs().mean(), TG.dummy_loss,
+                                       lambda logits, target, is_disc: logits.mean(), torch.zeros(1, 2, 3, 2, 2), hr)
+    TG.discriminator_step(disc, lambda logits, target, is_disc: logits.mean(), sr, hr)
+    assert [k for k, _ in seen] == ["model", "disc", "disc", "disc"]
+    assert all(d == VF.DT_BF16 for _, d in seen), seen    # the bf16 build without compute_dtype / $VSRLAB_AMD_DTYPE
+    assert VF.resolve_dtype() == VF.DT_F32

@@ -326,3 +326,54 @@ def test_training_glue_has_no_cpu_fallback():
         FusedAdam([torch.nn.Parameter(torch.zeros(4))])
     with pytest.raises(RuntimeError):
         resize(torch.zeros(1, 3, 8, 8), (2, 2))
+
+
+# ---- round-2 ADVICE: gradients that autograd left outside the arena are gathered BEFORE the exchange ----
+def _foreign_grad_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vsrlab_amd.optim import FusedAdam
+        from vsrlab_amd.parallel import FlatGradSync
+        torch.manual_seed(5)
+        lin = torch.nn.Linear(6, 3)
+        train = list(lin.parameters())
+        n = sum(p.numel() for p in train)
+        flat_g = torch.zeros(n)
+
+        class Arena:                                       # FusedAdam's arena bookkeeping on CPU tensors, its REAL gather method
+            gather_foreign_grads = FusedAdam.gather_foreign_grads
+
+        arena = Arena()
+        arena._params = train
+        o = 0
+        for p in train:
+            p._vsr_grad_slot = flat_g[o:o + p.numel()].view(p.shape)
+            p.grad = p._vsr_grad_slot
+            o += p.numel()
+        sync = FlatGradSync(flat_g, optimizer=arena)
+        lin.zero_grad()                                    # nn.Module.zero_grad: set_to_none=True -> autograd will allocate fresh .grad tensors
+        assert all(p.grad is None for p in train)
+        flat_g.fill_(123.0)                                # stale arena contents that must NOT be exchanged
+        x = torch.rand(4, 6, generator=torch.Generator().manual_seed(50 + rank))
+        lin(x).square().mean().backward()
+        local = torch.cat([p.grad.flatten() for p in train]).clone()
+        assert all(p.grad.data_ptr() != p._vsr_grad_slot.data_ptr() for p in train)
+        sync.all_reduce()
+        assert all(p.grad.data_ptr() == p._vsr_grad_slot.data_ptr() for p in train)      # re-pointed at the arena
+        locs = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(locs, local)
+        want = 0.5 * (locs[0] + locs[1])
+        assert float((flat_g - want).abs().max()) < 1e-6, float((flat_g - want).abs().max())
+        if rank == 0:
+            torch.save({"ok": torch.ones(1)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_sync_gathers_foreign_gradients_before_the_exchange(tmp_path):
+    out = str(tmp_path / "ok.pt")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_foreign_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    assert os.path.exists(out)

@@ -88,6 +88,35 @@ def test_fused_adam_skips_the_step_on_non_finite_gradients_and_weight_decay():
     assert rel_err(q2.detach().cpu(), p.detach()) < 2e-6
 
 
+@pytest.mark.gpu
+def test_fused_adam_skipped_step_count():
+    """round-2 ADVICE: the host-side step count advances on a device-skipped update (documented in FusedAdam.step);
+    rewind_skipped_step() restores what GradScaler.step + torch.optim.Adam would hold."""
+    dev = _gpu()
+    from vsrlab_amd.optim import FusedAdam
+    q = torch.nn.Parameter(torch.ones(64, device=dev))
+    opt = FusedAdam([q], lr=1e-2)
+    q.grad.fill_(0.5)
+    opt.step()
+    assert int(opt.state_dict()["state"][0]["step"]) == 1 and not opt.rewind_skipped_step()
+    q.grad.fill_(float("inf"))
+    before = q.detach().clone()
+    opt.step()
+    assert torch.equal(q.detach(), before)
+    assert int(opt.state_dict()["state"][0]["step"]) == 2          # the documented deviation
+    assert opt.rewind_skipped_step()
+    assert int(opt.state_dict()["state"][0]["step"]) == 1          # torch's count after a step GradScaler would have skipped
+    # the next real step then has torch's bias corrections
+    p = torch.nn.Parameter(torch.ones(64))
+    ref = torch.optim.Adam([p], lr=1e-2, betas=(0.9, 0.99))
+    for g in (0.5, 0.25):
+        p.grad = torch.full((64,), g)
+        ref.step()
+    q.grad.fill_(0.25)
+    opt.step()
+    assert rel_err(q.detach().cpu(), p.detach()) < 2e-6
+
+
 @pytest.mark.parametrize("shape,size", [((2, 3, 3, 64, 96), (16, 24)), ((1, 2, 3, 37, 53), (9, 13)), ((2, 3, 20, 28), (40, 56))])
 def test_resize_matches_interpolate(shape, size):
     """kornia.geometry.transform.resize(hr, (h, w)) = F.interpolate(bilinear, align_corners=False) on (..., H, W)."""

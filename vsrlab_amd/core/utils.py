@@ -59,6 +59,11 @@ def update_weights(model, loss, scaler, scheduler, optimizer, num_grad_acc, grad
     if not last:
         return
     if grad_sync is not None:
+        # gradients that reached p.grad through autograd instead of the arena (discriminator, cleaner, attention parameters;
+        # after nn.Module.zero_grad()'s set_to_none, or a user-assigned p.grad) must be IN the arena before it is exchanged:
+        # otherwise the all-reduce ships stale arena contents and step() then steps each rank on its own local gradient
+        if isinstance(optimizer, FusedAdam):
+            optimizer.gather_foreign_grads()
         grad_sync.all_reduce()
     if isinstance(optimizer, FusedAdam):
         if scaler is not None and scaler.is_enabled():

@@ -92,8 +92,11 @@ class FusedAdam(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != p._vsr_grad_slot.data_ptr():
                 p.grad = p._vsr_grad_slot
 
-    def _gather_foreign_grads(self):
-        # a gradient produced by an op that does not know the arena (p.grad re-assigned by autograd or by the user)
+    def gather_foreign_grads(self):
+        """Copy into the arena every gradient that an op which does not know the arena left in ``p.grad`` (re-assigned by
+        autograd after ``set_to_none``, or by the user), and re-point ``p.grad`` at its arena slot.  ``step()`` and
+        ``grad_norm()`` call it; a data-parallel exchange of ``flat_grads`` must call it FIRST (``update_weights`` and
+        ``FlatGradSync(optimizer=...)`` do)."""
         for p in self._params:
             slot = p._vsr_grad_slot
             if p.grad is None:
@@ -104,7 +107,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def grad_norm(self, grad_scale: float = 1.0) -> torch.Tensor:
         """``clip_grad_norm_``'s return value (global L2 norm of all gradients) as a 1-element device tensor."""
-        self._gather_foreign_grads()
+        self.gather_foreign_grads()
         out = torch.empty(1, dtype=torch.float32, device=self.flat_grads.device)
         lib = _lib.load()
         _lib.check(lib.vsr_grad_norm(_ptr(self.flat_grads), self._numel, float(grad_scale), _ptr(self._scratch), _ptr(out), _stream()),
@@ -115,12 +118,20 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None, max_grad_norm: Optional[float] = None, grad_scale: float = 1.0):
         """clip (``max_grad_norm`` or the constructor's; None = no clipping) + Adam, two launches.
         ``grad_scale`` multiplies the gradient first (1/num_grad_acc, 1/world_size after a SUM all-reduce, or a
-        GradScaler's inverse scale); a non-finite gradient norm skips the update like ``GradScaler.step``."""
+        GradScaler's inverse scale); a non-finite gradient norm skips the update like ``GradScaler.step``.
+
+        Step count after a skipped update: the kernel decides on the device whether the norm is finite, and this
+        method never synchronises with it, so the host-side ``step`` (and ``state_dict()['state'][i]['step']``)
+        advances on a skipped update as well, whereas ``GradScaler.step`` would not have called ``optimizer.step()``.
+        The bias corrections of later steps are then those of step+1 (a factor within 1e-2 of 1 after ~100 steps at
+        beta2 = 0.99).  bf16 / fp32 training without loss scaling does not produce inf/nan gradients in normal
+        operation; ``last_grad_norm`` (device tensor) lets a caller detect a skipped step and call
+        ``rewind_skipped_step()`` to restore torch's count.  Pinned by ``test_fused_adam_skipped_step_count``."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self._gather_foreign_grads()
+        self.gather_foreign_grads()
         g = self.param_groups[0]
         mx = self.max_grad_norm if max_grad_norm is None else max_grad_norm
         self._step += 1
@@ -132,6 +143,15 @@ class FusedAdam(torch.optim.Optimizer):
                                           _ptr(self.last_grad_norm), _stream()), "adam_clip_step")
         self._step_t.fill_(float(self._step))
         return loss
+
+    def rewind_skipped_step(self):
+        """If the last ``step()`` was skipped on the device (non-finite gradient norm), take its count back so that the step
+        count matches what ``GradScaler.step`` + ``torch.optim.Adam`` would hold.  Synchronises (reads ``last_grad_norm``)."""
+        if self._step > 0 and not bool(torch.isfinite(self.last_grad_norm).item()):
+            self._step -= 1
+            self._step_t.fill_(float(self._step))
+            return True
+        return False
 
     # checkpoints: torch.optim.Adam's layout in, flat buffers refreshed --------------------------- #
     def load_state_dict(self, state_dict):

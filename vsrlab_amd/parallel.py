@@ -24,14 +24,17 @@ class FlatGradSync:
     """``sync = FlatGradSync(optimizer.flat_grads, params=optimizer.flat_params)``; after ``loss.backward()``:
     ``sync.all_reduce()`` then ``optimizer.step()``.
 
-    grads / params: flat tensors (views are fine).  At construction the parameters are broadcast from rank 0 (DDP's
+    grads / params: flat tensors (views are fine).  ``optimizer``: the ``FusedAdam`` that owns the arena; gradients that
+    autograd left outside the arena (``p.grad`` re-assigned after ``zero_grad(set_to_none=True)``) are then gathered into
+    it before every exchange.  At construction the parameters are broadcast from rank 0 (DDP's
     start-up broadcast, so every replica starts from the same weights)."""
 
     def __init__(self, grads: torch.Tensor, params: Optional[torch.Tensor] = None, process_group=None,
-                 extra_buffers: Iterable[torch.Tensor] = ()):
+                 extra_buffers: Iterable[torch.Tensor] = (), optimizer=None):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("FlatGradSync needs an initialised torch.distributed process group")
         self.grads = grads
+        self.optimizer = optimizer               # a FusedAdam whose arena `grads` is: its foreign gradients are gathered before the exchange
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self._enabled = True
@@ -55,6 +58,8 @@ class FlatGradSync:
         """grads <- mean over ranks.  Returns the work handle when ``async_op`` (call ``.wait()`` before the step)."""
         if not self._enabled or self.world_size == 1:
             return None
+        if self.optimizer is not None:
+            self.optimizer.gather_foreign_grads()
         self.num_collectives += 1
         work = dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
