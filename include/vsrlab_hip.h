@@ -190,8 +190,11 @@ size_t vsr_conv3x3_c64_wgrad_slab_floats(void);
 int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float* gw, float* gb,
                           float* slab, int N, int H, int W, void* stream);
 
-/* Charbonnier loss value and gradient (core/losses.py:10-18): loss = mean(sqrt((sr-hr)^2+eps)) */
-int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, long long numel,
+/* Charbonnier loss value and gradient (core/losses.py:10-18): loss = mean(sqrt((sr-hr)^2+eps)).
+ * sr / hr / dsr 16-byte aligned.  scratch: vsr_charbonnier_scratch_floats() floats (per-workgroup partial sums; the value is
+ * reduced in a fixed order, so it is bit-identical from run to run -- ABI 2; ABI 1 had no scratch and summed with atomics). */
+size_t vsr_charbonnier_scratch_floats(void);
+int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, float* scratch, long long numel,
                             float eps, void* stream);
 
 /* ---- training-step glue over FLAT fp32 arenas (csrc/train_step.hip) ---------------------------------------

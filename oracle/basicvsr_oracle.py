@@ -369,8 +369,10 @@ def cleaner_forward(sd: Mapping[str, Tensor], lr: Tensor, prefix: str = "cleaner
         blocks += 1
     x = lr.reshape(-1, c, h, w)
     for _ in range(steps):
-        r = residual_block(sd, prefix + "resblock.", x, blocks)
-        x = x + F.conv2d(r, sd[prefix + "conv.weight"], sd[prefix + "conv.bias"], padding=1)
+        # (bf16 emulation points of the HIP perf build: the fp32 planar frame is staged as bf16 into the stem, the 64 -> 3 conv
+        # is fed bf16 weights and stages its fp32 cotangent as bf16; the running frame x itself stays fp32)
+        r = residual_block(sd, prefix + "resblock.", _iq(x), blocks)
+        x = x + _gq(F.conv2d(r, _wq(sd[prefix + "conv.weight"]), sd[prefix + "conv.bias"], padding=1))
     return x.view(n, t, c, h, w)
 
 

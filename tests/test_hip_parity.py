@@ -46,7 +46,7 @@ DTYPES = ["fp32", "bf16"]
 def test_library_loaded_and_abi():
     import vsrlab_amd
     lib = vsrlab_amd._lib.load()
-    assert lib.vsr_abi_version() == 1
+    assert lib.vsr_abi_version() == 2
     _gpu()
 
 
@@ -241,6 +241,18 @@ def _noise_floor_check(grads_hip, grads_emu, ref, max_glob_ratio=1.5, max_tensor
     if max_tensor_ratio is not None:
         assert worst[0] <= max_tensor_ratio, ("per-tensor", worst)
     return e_hip / max(e_emu, floor), worst[0], worst[1]
+
+
+FP32_FLOOR = 2e-4      # fp32 criterion: per-tensor errors below this (plain summation-order rounding, no mask flip) all count as "at the floor"
+
+
+def _fp32_noise_floor_check(grads_hip, grads_o32, ref64, max_glob_ratio=1.5, max_tensor_ratio=2.5):
+    """fp32 criterion (round-2 VERDICT weak #1), the same construction as the bf16 one: the HIP fp32 build and the fp32 CPU oracle
+    are two fp32 evaluations of the net; both are compared with the fp64 oracle, and the HIP build's error may not exceed the
+    fp32 oracle's own error by more than the stated ratios.  (ReLU / LeakyReLU mask flips make two correct fp32 evaluations
+    differ by up to ~1e-2 on single tensors at depth 61 x 5 frames: a fixed tolerance either hides a 1 % bug or fails a
+    correct kernel; this one scales with the net under test.)"""
+    return _noise_floor_check(grads_hip, grads_o32, ref64, max_glob_ratio=max_glob_ratio, max_tensor_ratio=max_tensor_ratio, floor=FP32_FLOOR)
 
 
 # Gradient tolerances.  ReLU / LeakyReLU masks are discontinuous, so a pre-activation perturbed by eps
@@ -455,11 +467,14 @@ def test_basicvsr_input_gradient_vs_golden():
     assert rel_l2(lg.grad, lo.grad) < 1e-4, rel_l2(lg.grad, lo.grad)
 
 
-def test_realbasicvsr_training_vs_oracle():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_realbasicvsr_training_vs_oracle(dtype):
     """sr, lq = RealBasicVSR(lr) with gradients of a two-term loss (core/utils.py:235-240 has one Charbonnier term on
     each output) for EVERY trainable tensor: the pre-clean stack's backward (3 iterations sharing their weights), fed by
-    the gradient w.r.t. lq from BasicVSR.  fp32 build vs the fp64 oracle (itself pinned to the reference's autocast run
-    by tests/test_oracle_golden.py).  t = 3 carries SPyNet's fp32 mask noise in d lq; t = 1 has no flow path and is sharp."""
+    the gradient w.r.t. lq from BasicVSR.  Reference = the fp64 oracle (itself pinned to the reference's autocast run by
+    tests/test_oracle_golden.py).  fp32 build: error <= 1.5 x (per tensor 2.5 x) the fp32 oracle's own error; bf16 build: the
+    same against the bf16-storage-emulating oracle (BASELINE config 3's generator side, realbasicvsr.py:24-30).
+    t = 3 carries SPyNet's mask noise in d lq; t = 1 has no flow path."""
     from helpers import realbasicvsr_shapes, realbasicvsr_oracle_grads
     from vsrlab_amd.vsr.models.RealBasicVSR.realbasicvsr import RealBasicVSR
     dev = _gpu()
@@ -467,10 +482,10 @@ def test_realbasicvsr_training_vs_oracle():
     m = RealBasicVSR(2, mid_channels=64, upscale=4, res_blocks=2, pretrained_flow=False, train_flow=False)
     m.load_state_dict(sd32, strict=True)
     m = m.to(dev)
-    m.basicvsr.compute_dtype = "fp32"
-    os.environ["VSRLAB_AMD_DTYPE"] = "fp32"
+    m.basicvsr.compute_dtype = dtype
+    os.environ["VSRLAB_AMD_DTYPE"] = dtype
     try:
-        for shape, t_glob, t_worst in (((1, 3, 3, 24, 40), 2e-2, 1e-1), ((2, 1, 3, 20, 36), 1e-3, 1e-2)):
+        for shape in ((1, 3, 3, 24, 40), (2, 1, 3, 20, 36)):
             n, t, _, h, w = shape
             lr = rand(14, *shape)
             cot_sr = rand(15, n, t, 3, 4 * h, 4 * w, lo=-1, hi=1)
@@ -482,14 +497,22 @@ def test_realbasicvsr_training_vs_oracle():
             (torch.mean(sr * cot_sr.to(dev)) + torch.mean(lq * cot_lq.to(dev))).backward()
             sd64 = {k: v.double() for k, v in sd32.items()}
             sr_o, lq_o, ref = realbasicvsr_oracle_grads(sd64, lr.double(), cot_sr.double(), cot_lq.double())
-            assert rel_err(lq, lq_o) < 1e-4 and rel_err(sr, sr_o) < 1e-3
             grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
             assert set(grads) == set(ref)
-            glob, worst, cos = _grad_report(grads, ref)
-            assert glob < t_glob, (shape, glob, worst)
-            assert worst[0] < t_worst, (shape, worst)
             cl = {k: v for k, v in ref.items() if k.startswith("cleaner.")}
-            assert len(cl) == 12 and _grad_report(grads, cl)[0] < t_glob
+            assert len(cl) == 12
+            if dtype == "fp32":
+                assert rel_err(lq, lq_o) < 1e-4 and rel_err(sr, sr_o) < 1e-3
+                _, _, g32 = realbasicvsr_oracle_grads(sd32, lr, cot_sr, cot_lq)
+                _fp32_noise_floor_check(grads, g32, ref)
+                _fp32_noise_floor_check({k: grads[k] for k in cl}, {k: g32[k] for k in cl}, cl)
+            else:
+                with O.emulate_bf16():
+                    sr_e, lq_e, g_e = realbasicvsr_oracle_grads(sd32, lr, cot_sr, cot_lq)
+                assert rel_err(lq, lq_o) <= 1.5 * max(rel_err(lq_e, lq_o), 1e-3), (rel_err(lq, lq_o), rel_err(lq_e, lq_o))
+                assert rel_err(sr, sr_o) <= 1.5 * max(rel_err(sr_e, sr_o), 1e-3), (rel_err(sr, sr_o), rel_err(sr_e, sr_o))
+                _noise_floor_check(grads, g_e, ref, max_glob_ratio=1.5, max_tensor_ratio=2.5)
+                _noise_floor_check({k: grads[k] for k in cl}, {k: g_e[k] for k in cl}, cl, max_glob_ratio=1.5, max_tensor_ratio=2.5)
     finally:
         del os.environ["VSRLAB_AMD_DTYPE"]
 
@@ -531,10 +554,9 @@ def test_basicvsr_config1_all_grads_vs_oracle(dtype):
         loss = CharbonnierLoss()(sr.to(dev), hr.to(dev))
         assert abs(float(loss) - float(loss_o)) < 1e-4 * float(loss_o)
         assert set(grads) == set(grads_o)
-        glob, worst, cos = _grad_report(grads, grads_o)
-        assert glob < 2e-3, (glob, worst)
-        assert worst[0] < 2e-2, worst
-        assert cos > 0.99999
+        _, _, grads_x, _ = _config1_oracle("fp64")
+        _fp32_noise_floor_check(grads, grads_o, grads_x)
+        assert _grad_report(grads, grads_x)[2] > 0.99999
     else:
         sr_x, loss_x, grads_x, hr = _config1_oracle("fp64")
         sr_e, loss_e, grads_e, _ = _config1_oracle("emu")
@@ -549,7 +571,7 @@ _C540 = {}
 
 
 def _oracle_540(kind):
-    """540x960, t=3, 2 blocks on the CPU oracle (fp32 arithmetic; 'emu' = with bf16 storage), once per session."""
+    """540x960, t=3, 2 blocks on the CPU oracle (fp32 arithmetic; 'emu' = with bf16 storage; 'fp64' = the exact one), once per session."""
     if kind not in _C540:
         shape = (1, 3, 3, 540, 960)
         sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4))
@@ -557,6 +579,8 @@ def _oracle_540(kind):
         if kind == "emu":
             with O.emulate_bf16():
                 sr, _, g = O.fwd_bwd(sd, lrs, cot, cot=cot)
+        elif kind == "fp64":
+            sr, _, g = O.fwd_bwd({k: v.double() for k, v in sd.items()}, lrs.double(), cot.double(), cot=cot.double())
         else:
             sr, _, g = O.fwd_bwd(sd, lrs, cot, cot=cot)
         _C540[kind] = (sr, g)
@@ -576,9 +600,7 @@ def test_basicvsr_540p_vs_oracle(dtype):
     assert set(grads) == set(g_o)
     if dtype == "fp32":
         assert rel_err(sr, sr_o) < 1e-3
-        glob, worst, cos = _grad_report(grads, g_o)
-        assert glob < 2e-3, (glob, worst)
-        assert worst[0] < 2e-2, worst
+        _fp32_noise_floor_check(grads, g_o, _oracle_540("fp64")[1])
     else:
         sr_e, g_e = _oracle_540("emu")
         assert rel_err(sr, sr_o) <= 1.5 * max(rel_err(sr_e, sr_o), 1e-3)
@@ -588,9 +610,8 @@ def test_basicvsr_540p_vs_oracle(dtype):
 
 def test_config2_full_size_properties():
     """BASELINE config 2 at FULL size through the C ABI (n=1, t=7, 540x960, 30 blocks, bf16: the benchmarked
-    configuration, ~128 GiB arena): finite outputs; a second backward on the same retained forward reproduces the
-    reconstruction gradients bit for bit (they are computed before any warp scatter) and every other tensor to
-    atomic-order noise; the backward is linear in the cotangent.  One forward, four backwards."""
+    configuration, ~128 GiB arena): finite outputs; a second backward on the same retained forward reproduces EVERY gradient
+    bit for bit; the backward is linear in the cotangent.  One forward, four backwards."""
     dev = _gpu()
     import vsrlab_amd
     from vsrlab_amd import functional as VF
@@ -625,19 +646,12 @@ def test_config2_full_size_properties():
     g12 = bwd(c12)
     del c12
     assert len(g1) == n_train == 254
-    recon = [k for k in g1 if k.startswith(("conv_last", "upsample", "point_conv"))]
-    assert len(recon) == 10
     for k in g1:
         assert bool(torch.isfinite(g1[k]).all()) and float(g1[k].abs().max()) > 0, k
-        if k in recon:
-            assert torch.equal(g1[k], g1b[k]), k                 # no atomics upstream of these
-        else:
-            # warp scatter: fp32 atomic ORDER noise, but rounded to bf16 after every one of the 60 dgrads of 7 frames
-            # (a last-bit difference flips bf16 roundings and ReLU masks downstream).  Measured at this depth: up to
-            # 3e-2 on a 64-element bias gradient, 7e-3 on the deepest weight tensor; 1e-4 at t=2 / 2 blocks.
-            assert rel_l2(g1b[k], g1[k]) < 1e-1, k
-    trunk = sorted(k for k in g1 if k not in recon)
-    assert rel_l2(torch.cat([g1b[k].flatten() for k in trunk]), torch.cat([g1[k].flatten() for k in trunk])) < 1.5e-2
+        # SURVEY 5 "determinism test": nothing in a frozen-flow backward depends on an arrival order any more -- the warp adjoint is
+        # a gather, its far-source share is summed in 64-bit fixed point (integer adds are associative), weight gradients are
+        # reduced from per-workgroup slabs in index order -- so a repeat is bit-identical for all 254 tensors at the benchmarked size
+        assert torch.equal(g1[k], g1b[k]), k
     cat = lambda d: torch.cat([d[k].flatten() for k in sorted(d)])
     # every product dY*X is formed from bf16-rounded activation gradients: linear up to bf16 rounding
     assert rel_l2(cat(g12), 0.5 * cat(g1) + cat(g2)) < 3e-2
@@ -748,6 +762,49 @@ def test_realbasicvsr_inference_vs_golden(dtype):
     assert rel_err(sr, g["sr"]) < tol(dtype, 1e-3, 3e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_far_flows_match_the_oracle_and_repeat_bit_for_bit(dtype):
+    """Flows longer than the gather radius of the warp adjoint (|flow| > 4 px: elementwise.hip warp_bwd_far_kernel) mixed with
+    short ones: a bias on SPyNet's finest level lengthens dx, so about half of the sources take the far path (64-bit
+    fixed-point atomics) and part the gather.  Gradients against the oracle at the noise floor, and two independent
+    forward + backward runs agree bit for bit (round-2 VERDICT #2: the far share used float atomics)."""
+    dev = _gpu()
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    shape = (1, 3, 3, 48, 64)
+    sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4))
+    sd["spynet.basic_module.5.basic_module.4.conv.0.bias"] = torch.tensor([1.0, 0.0])
+    lrs, cot = rand(81, *shape), rand(82, 1, 3, 3, 192, 256, lo=-1, hi=1)
+    fb, ff = O.basicvsr_compute_flow(sd, lrs)
+    far = float(((fb.abs() > 4).any(dim=2).float().mean() + (ff.abs() > 4).any(dim=2).float().mean()) / 2)
+    assert 0.05 < far < 0.95, far                                   # both paths are exercised
+
+    def run():
+        m = BasicVSR(64, 2, 4, False, False)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev)
+        m.compute_dtype = dtype
+        sr = m(lrs.to(dev))
+        torch.mean(sr * cot.to(dev)).backward()
+        return sr.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+    sr, grads = run()
+    sr2, grads2 = run()
+    assert torch.equal(sr, sr2)
+    for k in grads:
+        assert torch.equal(grads[k], grads2[k]), k
+    sd64 = {k: v.double() for k, v in sd.items()}
+    sr_x, _, g_x = O.fwd_bwd(sd64, lrs.double(), cot.double(), cot=cot.double())
+    if dtype == "fp32":
+        sr_o, _, g_o = O.fwd_bwd(sd, lrs, cot, cot=cot)
+        assert rel_err(sr, sr_x) < 1e-3
+        _fp32_noise_floor_check(grads, g_o, g_x)
+    else:
+        with O.emulate_bf16():
+            sr_e, _, g_e = O.fwd_bwd(sd, lrs, cot, cot=cot)
+        assert rel_err(sr, sr_x) <= 1.5 * max(rel_err(sr_e, sr_x), 1e-3)
+        _noise_floor_check(grads, g_e, g_x, max_glob_ratio=1.5, max_tensor_ratio=2.5)
+
+
 def test_long_clip_more_than_8_frames_fp32():
     """t = 10 > VSR_WG_MAXSEG: the per-layer weight-gradient launches are split over two segment batches and
     accumulated; odd frame size; fp32 build against the fp32 oracle."""
@@ -755,10 +812,11 @@ def test_long_clip_more_than_8_frames_fp32():
     shape = (1, 10, 3, 20, 36)
     m, lrs, cot, sr, grads = _run_basicvsr("fp32", 64, 1, shape, 61, 62, dev)
     sd = O.keyed_state_dict(O.basicvsr_param_shapes(64, 1, 4))
-    sr_o, _, grads_o = O.fwd_bwd(sd, lrs, rand(63, 1, 10, 3, 80, 144), cot=cot)
+    hr = rand(63, 1, 10, 3, 80, 144)
+    sr_o, _, grads_o = O.fwd_bwd(sd, lrs, hr, cot=cot)
+    _, _, grads_x = O.fwd_bwd({k: v.double() for k, v in sd.items()}, lrs.double(), hr.double(), cot=cot.double())
     assert rel_err(sr, sr_o) < 1e-3
-    glob, worst, cos = _grad_report(grads, grads_o)
-    assert glob < 2e-3 and worst[0] < 2e-2, (glob, worst)
+    _fp32_noise_floor_check(grads, grads_o, grads_x)
 
 
 def test_standalone_module_forwards_vs_oracle():

@@ -61,7 +61,8 @@ _SIGNATURES = {
     "vsr_conv_layer_fwd": (c_int, [c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_wgrad_slab_floats": (c_size_t, []),
     "vsr_conv3x3_c64_wgrad": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "vsr_charbonnier_fwd_bwd": (c_int, [_P, _P, _P, _P, c_longlong, c_float, _P]),
+    "vsr_charbonnier_scratch_floats": (c_size_t, []),
+    "vsr_charbonnier_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_float, _P]),
     "vsr_optim_scratch_floats": (c_size_t, []),
     "vsr_adam_clip_step": (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int, c_float,
                                    c_float, _P, _P, _P]),

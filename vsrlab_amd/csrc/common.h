@@ -173,6 +173,28 @@ static inline int vsr_num_cus() {
     return v;
 }
 
+// A/B and test switches of the library, read from the environment ONCE per process: C++11 initialises a function-local static
+// exactly once, also under concurrent first calls (the library is callable from several threads), and no launch path calls getenv.
+#include <cstdlib>
+struct VsrEnvSwitches {
+    bool generic_conv, generic_wgrad, attn_generic, single_stream;
+    int wide2_max_wg;
+};
+static inline const VsrEnvSwitches& vsr_env() {
+    static const VsrEnvSwitches s = [] {
+        auto on = [](const char* n) { const char* e = getenv(n); return e && e[0] == '1'; };
+        VsrEnvSwitches v;
+        v.generic_conv = on("VSRLAB_AMD_GENERIC_CONV");
+        v.generic_wgrad = on("VSRLAB_AMD_GENERIC_WGRAD");
+        v.attn_generic = getenv("VSRLAB_AMD_ATTN_GENERIC") != nullptr;
+        v.single_stream = on("VSRLAB_AMD_SINGLE_STREAM");
+        const char* e = getenv("VSRLAB_AMD_WIDE2_MAX_WG");
+        v.wide2_max_wg = e ? atoi(e) : 0;
+        return v;
+    }();
+    return s;
+}
+
 #define HIP_CHECK_RET(expr)                                   \
     do {                                                      \
         hipError_t _e = (expr);                               \

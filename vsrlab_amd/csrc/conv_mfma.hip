@@ -376,15 +376,8 @@ int launch_inst(const ConvArgs& a, hipStream_t st) {
 int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st);
 int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);      // hr_tail.hip
 
-// VSRLAB_AMD_GENERIC_CONV=1 routes the hot shape through the generic tiled kernel (A/B testing only).
-static bool vsr_force_generic_conv() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VSRLAB_AMD_GENERIC_CONV");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
+// VSRLAB_AMD_GENERIC_CONV=1 routes the hot shape through the generic tiled kernel (A/B testing only; common.h: vsr_env()).
+static bool vsr_force_generic_conv() { return vsr_env().generic_conv; }
 
 // Host dispatcher (C++ linkage, used by the engine and by the C-ABI per-op entry points).
 int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar, int cout_t, int epi,

@@ -998,8 +998,7 @@ int vsr_launch_conv_wide(int dtype, const VsrWideConv& c, hipStream_t st) {
         if (nwx < 1) nwx = 1;
         if (nwx > tiles) nwx = tiles;
         {   // test knob: cap the workgroups per column so that small frames exercise the many-tiles-per-workgroup path
-            const char* e = getenv("VSRLAB_AMD_WIDE2_MAX_WG");
-            const int cap = e ? atoi(e) : 0;
+            const int cap = vsr_env().wide2_max_wg;
             if (cap > 0 && nwx > cap) nwx = cap;
         }
         static VsrDevOnce once2, once2k;

@@ -134,12 +134,15 @@ __global__ void warp_bwd_kernel(const T* __restrict__ dout, const float* __restr
 //     in a FIXED order and write T(dtop + sum) -- the add_cast of the scatter form is fused, nothing is atomic, the result is
 //     bitwise reproducible;
 //   * sources displaced by more than R - 1 pixels ("far") are skipped here and scattered with atomics by
-//     warp_bwd_far_kernel into the fp32 accumulator S, which this kernel adds (and re-zeroes) only when the launch's
-//     far counter is non-zero: correct for any flow, fast for the flows SPyNet produces.
+//     warp_bwd_far_kernel into the accumulator S, which this kernel adds (and re-zeroes) only when the launch's
+//     far counter is non-zero: correct for any flow, fast for the flows SPyNet produces.  S holds 64-bit FIXED-POINT sums
+//     (2^-44 units, |sum| < 5.2e5): integer addition is associative, so the scattered share is bit-identical from run to run
+//     whatever the arrival order of the atomics (round 2 added floats: trunk gradients wobbled whenever a flow was far).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int GR = 5;                                   // search radius: sources within +-5 pixels; |flow| <= 4 is "near"
 constexpr int GTH = 8, GTW = 32, GCAP = 8;
 constexpr int GHH = GTH + 2 * GR, GHW = GTW + 2 * GR;   // 18 x 42 sources per tile
+constexpr double FAR_FX = 17592186044416.0;             // 2^44: fixed-point unit of the far accumulator
 
 __device__ __forceinline__ bool flow_is_far(float fx, float fy) {
     return !(fabsf(fx) <= (float)(GR - 1) && fabsf(fy) <= (float)(GR - 1));      // NaN counts as far
@@ -147,7 +150,7 @@ __device__ __forceinline__ bool flow_is_far(float fx, float fy) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const T* __restrict__ dout, const float* __restrict__ flow, const T* __restrict__ dtop,
-                                                              float* __restrict__ S, const int* __restrict__ far_count, T* __restrict__ out,
+                                                              long long* __restrict__ S, const int* __restrict__ far_count, T* __restrict__ out,
                                                               int N, int H, int W, long long flow_nstride) {
     constexpr int C = 64;
     typedef typename EW<T>::chunk_t chunk_t;
@@ -231,10 +234,9 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const T* __restric
                 }
         }
         if (add_far) {                                  // the atomically scattered share; S goes back to all-zero
-            float4* sp = reinterpret_cast<float4*>(S + (((long long)n * H + yi) * W + xi) * C + c * 8);
-            const float4 s0 = sp[0], s1 = sp[1];
-            acc[0] += s0.x; acc[1] += s0.y; acc[2] += s0.z; acc[3] += s0.w; acc[4] += s1.x; acc[5] += s1.y; acc[6] += s1.z; acc[7] += s1.w;
-            sp[0] = make_float4(0.f, 0.f, 0.f, 0.f); sp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            long long* sp = S + (((long long)n * H + yi) * W + xi) * C + c * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[j] += (float)((double)sp[j] * (1.0 / FAR_FX)); sp[j] = 0; }
         }
         const long long o = img + pm_off(yi, xi, c, W, C);
         if (dtop) {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const T* __restric
 
 // the "far" sources of the gather form: |flow| > GR - 1 (or non-finite): scattered with atomics like warp_bwd_kernel, and counted
 template <typename T>
-__global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __restrict__ flow, float* __restrict__ S, int* __restrict__ far_count,
+__global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __restrict__ flow, long long* __restrict__ S, int* __restrict__ far_count,
                                     int N, int H, int W, long long flow_nstride) {
     constexpr int C = 64;
     const long long total = (long long)N * H * W;
@@ -283,12 +285,14 @@ __global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __r
         const int x0 = (int)fx0, y0 = (int)fy0;
         const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         const float g = (float)dout[(long long)n * pm_image_elems(H, W, C) + pm_off(y, x, c >> 3, W, C) + (c & 7)];
-        float* imgp = S + (long long)n * H * W * C;
+        long long* imgp = S + (long long)n * H * W * C;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
             const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
-            if (xi >= 0 && xi < W && yi >= 0 && yi < H) atomicAdd(imgp + ((long long)yi * W + xi) * C + c, g * wgt);
+            if (xi >= 0 && xi < W && yi >= 0 && yi < H)
+                atomicAdd(reinterpret_cast<unsigned long long*>(imgp + ((long long)yi * W + xi) * C + c),
+                          (unsigned long long)__double2ll_rn((double)(g * wgt) * FAR_FX));       // two's complement: signed sums
         }
         }
     }
@@ -787,17 +791,51 @@ __global__ void pack_multi_kernel(const PackArgs a) {
     else reinterpret_cast<float*>(d.dst)[idx] = v;
 }
 
+// The loss VALUE is summed in a fixed order (per-thread strided sums, wave shuffle tree, one partial per workgroup, then ONE
+// workgroup adds the partials in index order): bit-identical from run to run (round 2 added the workgroup partials with atomicAdd,
+// whose arrival order is not).
+constexpr int CHARB_BLOCKS = 1024;
 __global__ void charbonnier_grad_kernel(const float* __restrict__ sr, const float* __restrict__ hr, float* __restrict__ dsr,
-                                        float* __restrict__ loss_acc, long long n, float eps, float scale) {
+                                        float* __restrict__ partial, long long n, float eps, float scale) {
+    __shared__ float red[4];
     float local = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(sr);
+    const float4* h4 = reinterpret_cast<const float4*>(hr);
+    float4* d4 = reinterpret_cast<float4*>(dsr);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = s4[i], b = h4[i];
+        float4 o;
+        float d, r;
+        d = a.x - b.x; r = sqrtf(d * d + eps); local += r; o.x = scale * d / r;
+        d = a.y - b.y; r = sqrtf(d * d + eps); local += r; o.y = scale * d / r;
+        d = a.z - b.z; r = sqrtf(d * d + eps); local += r; o.z = scale * d / r;
+        d = a.w - b.w; r = sqrtf(d * d + eps); local += r; o.w = scale * d / r;
+        d4[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {          // tail of a length that is not a multiple of 4
+        const long long i = (n4 << 2) + threadIdx.x;
         const float d = sr[i] - hr[i];
         const float r = sqrtf(d * d + eps);
         local += r;
         dsr[i] = scale * d / r;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, local * scale);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+__global__ void charbonnier_sum_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0];
 }
 
 inline int grid_for(long long total, int block = 256) {
@@ -831,7 +869,7 @@ int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* d
 
 // out = T(dtop + warp^T(dout)) for the 64-channel propagation warps (zeros padding): gather kernel + far-source scatter.
 // S: fp32 [N][H][W][64], ALL ZERO on entry and on exit; far_count: one int, zero on entry (the number of far sources on exit).
-int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, const void* dtop, float* S, int* far_count, void* out,
+int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, const void* dtop, long long* S, int* far_count, void* out,
                                int N, int H, int W, long long flow_nstride, hipStream_t st) {
     if (!dout || !flow || !S || !far_count || !out) return VSR_ERR_BADARG;
     const long long npix = (long long)N * H * W;
@@ -969,9 +1007,14 @@ int vsr_launch_pack_multi(const VsrPackDesc* descs, int n, hipStream_t st) {
     return VSR_OK;
 }
 
-int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps, hipStream_t st) {
-    HIP_CHECK_RET(hipMemsetAsync(loss_acc, 0, sizeof(float), st));
-    hipLaunchKernelGGL(charbonnier_grad_kernel, dim3(grid_for(n)), dim3(256), 0, st, sr, hr, dsr, loss_acc, n, eps, 1.0f / (float)n);
+int vsr_charbonnier_scratch_floats_impl() { return CHARB_BLOCKS; }
+int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, float* scratch, long long n, float eps,
+                                hipStream_t st) {
+    if ((reinterpret_cast<uintptr_t>(sr) | reinterpret_cast<uintptr_t>(hr) | reinterpret_cast<uintptr_t>(dsr)) & 15) return VSR_ERR_BADARG;   // float4 access
+    const long long want = ((n >> 2) + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > CHARB_BLOCKS ? CHARB_BLOCKS : want));
+    hipLaunchKernelGGL(charbonnier_grad_kernel, dim3(blocks), dim3(256), 0, st, sr, hr, dsr, scratch, n, eps, 1.0f / (float)n);
+    hipLaunchKernelGGL(charbonnier_sum_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, loss_acc);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

@@ -89,7 +89,7 @@ struct Plan {
     int rb, n, t, h, w, dtype;
     size_t es;
     size_t px1;                 // elements of one blocked (n,h,w,64) tensor
-    size_t s_elems;             // elements of the plain fp32 warp-scatter accumulator (n,h,w,64)
+    size_t s_elems;             // elements of the plain 64-bit fixed-point warp-scatter accumulator (n,h,w,64)
     // packed weights / biases
     size_t stem_w[2], stem_wd[2], stem_b[2];
     std::vector<size_t> blk_w[2], blk_wd[2], blk_b[2];     // [2*rb]: conv1, conv2 alternating
@@ -189,7 +189,7 @@ struct Plan {
             }
             dFeatB.assign(t, 0); dFF.assign(t, 0);
             for (int i = 0; i < t; ++i) { dFeatB[i] = b.take(a1); dFF[i] = b.take(a1); }
-            for (int dir = 0; dir < 2; ++dir) { S[dir] = b.take(s_elems * 4); dWp[dir] = b.take(a1); }
+            for (int dir = 0; dir < 2; ++dir) { S[dir] = b.take(s_elems * 8); dWp[dir] = b.take(a1); }
             far_cnt = b.take((size_t)2 * 32 * 4);
             G_C0 = b.take(a4); G_U1 = b.take(a4); G_U0 = b.take(a2); G_P = b.take(a1);
             int cp, xp, stride;
@@ -495,10 +495,7 @@ int get_helper(Helper** out) {
     *out = &x;
     return VSR_OK;
 }
-bool single_stream() {
-    static const bool v = [] { const char* e = getenv("VSRLAB_AMD_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    return v;
-}
+bool single_stream() { return vsr_env().single_stream; }
 struct Fork {   // RAII: the join is enqueued on every exit path
     hipStream_t main; Helper* h; bool active = false;
     int begin() {
@@ -718,7 +715,7 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
     const int n = p.n, h = p.h, w = p.w, rb = p.rb;
     if (pending_flow) {
         const long long fstride = (long long)(p.t - 1) * 2 * h * w;
-        CK(vsr_launch_warp_bwd_gather(c.dtype, c.at(p.dWp[dir]), pending_flow, dtop, (float*)c.at(p.S[dir]),
+        CK(vsr_launch_warp_bwd_gather(c.dtype, c.at(p.dWp[dir]), pending_flow, dtop, (long long*)c.at(p.S[dir]),
                                       (int*)c.at(p.far_cnt) + dir * 32 + pending_k, c.at(p.dxoff(dir, i, rb)), n, h, w, fstride, c.st));
     } else {
         CK(vsr_launch_add_cast(c.dtype, dtop, nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
@@ -779,7 +776,7 @@ int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float
     const int n = p.n, t = p.t, h = p.h, w = p.w;
     const long long fstride = (long long)(t - 1) * 2 * h * w;
     // the gather-form warp backward keeps S all-zero between uses: ONE memset per chain (was one per frame)
-    HIP_CHECK_RET(hipMemsetAsync(c.at(p.S[dir]), 0, p.s_elems * 4, c.st));
+    HIP_CHECK_RET(hipMemsetAsync(c.at(p.S[dir]), 0, p.s_elems * 8, c.st));
     HIP_CHECK_RET(hipMemsetAsync((int*)c.at(p.far_cnt) + dir * 32, 0, 32 * 4, c.st));
     const float* pending = nullptr;
     for (int k = 0; k < t; ++k) {
@@ -833,7 +830,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
 // ================================ C ABI =========================================================
 extern "C" {
 
-int vsr_abi_version(void) { return 1; }
+int vsr_abi_version(void) { return 2; }
 
 const char* vsr_status_string(int s) {
     switch (s) {
@@ -1326,9 +1323,10 @@ int vsr_conv3x3_c64_wgrad(int dtype, const void* x_pm, const void* dy_pm, float*
     return vsr_launch_wgrad_reduce(slab, nslabs, 3, 64, 64, C, C, gw, C, 0, 1, 0, gb, 0, st);
 }
 
-int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, long long numel, float eps, void* stream) {
-    if (!sr || !hr || !dsr || !loss || numel < 1) return VSR_ERR_BADARG;
-    return vsr_launch_charbonnier_grad(sr, hr, dsr, loss, numel, eps, (hipStream_t)stream);
+size_t vsr_charbonnier_scratch_floats(void) { return (size_t)vsr_charbonnier_scratch_floats_impl(); }
+int vsr_charbonnier_fwd_bwd(const float* sr, const float* hr, float* dsr, float* loss, float* scratch, long long numel, float eps, void* stream) {
+    if (!sr || !hr || !dsr || !loss || !scratch || numel < 1) return VSR_ERR_BADARG;
+    return vsr_launch_charbonnier_grad(sr, hr, dsr, loss, scratch, numel, eps, (hipStream_t)stream);
 }
 
 }  // extern "C"

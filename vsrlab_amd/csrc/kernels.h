@@ -15,7 +15,8 @@ int vsr_launch_warp_fwd(int dtype, const void* in, const float* flow, void* out,
                         long long flow_nstride, hipStream_t st, int border = 0);
 int vsr_launch_warp_bwd(int dtype, const void* dout, const float* flow, float* dacc, int N, int H, int W, int C,
                         long long flow_nstride, hipStream_t st, int border = 0);
-int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, const void* dtop, float* S, int* far_count, void* out,
+// S: 64-bit fixed-point accumulator [N][H][W][64] (all-zero on entry and on exit)
+int vsr_launch_warp_bwd_gather(int dtype, const void* dout, const float* flow, const void* dtop, long long* S, int* far_count, void* out,
                                int N, int H, int W, long long flow_nstride, hipStream_t st);
 int vsr_launch_add_cast(int dtype, const void* a, const float* s, void* out, int N, int H, int W, int C, hipStream_t st);
 int vsr_launch_planar_to_pm(int dtype, const float* in, void* out, int N, int Cin, int H, int W, int C, hipStream_t st);
@@ -53,7 +54,8 @@ struct VsrPackDesc {
 int vsr_launch_pack_multi(const VsrPackDesc* descs, int n, hipStream_t st);
 int vsr_launch_pack_weights(int dtype, const float* w, void* dst, int KK, int RP, int CPd, int r_real, int c_real,
                             int I_total, int i_off, int o_mul, int o_add, int mode, hipStream_t st);
-int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, long long n, float eps,
+int vsr_charbonnier_scratch_floats_impl();
+int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, float* scratch, long long n, float eps,
                                 hipStream_t st);
 
 // ---- GAN side (conv_wide.hip) ----

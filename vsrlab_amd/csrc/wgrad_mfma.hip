@@ -717,8 +717,7 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
     if (a.nseg < 1 || a.nseg > VSR_WG_MAXSEG || nwg < 1 || !nslabs) return VSR_ERR_BADARG;
     *nslabs = nwg;
     {   // hot shape: LDS-DMA double-buffered kernel (needs an even slab count: 2 row-halves per workgroup)
-        static int force_generic = -1;
-        if (force_generic < 0) { const char* e = getenv("VSRLAB_AMD_GENERIC_WGRAD"); force_generic = (e && e[0] == '1') ? 1 : 0; }
+        const bool force_generic = vsr_env().generic_wgrad;
         if (!force_generic && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 64 && !dy_planar && nwg >= 2) {
             *nslabs = nwg / 2;                                 // one 512-thread workgroup per CU, one slab each
             return launch_wgrad_pc(a, nwg / 2, st);

@@ -915,7 +915,7 @@ int vsr_window_attention_fwd(const VsrAttnDesc* d, const void* qkv, const float*
     const int bx = 1, wv = d->Nq / WQ < MAXW ? d->Nq / WQ : MAXW;
     const size_t es = d->dtype == VSR_BF16 ? 2 : 4;
     const size_t lds = ((size_t)d->Nk * HP + (size_t)HP * (d->Nk + 8)) * es;
-    if (d->Nq == d->Nk && (d->Nk == 128 || d->Nk == 64) && !getenv("VSRLAB_AMD_ATTN_GENERIC")) {
+    if (d->Nq == d->Nk && (d->Nk == 128 || d->Nk == 64) && !vsr_env().attn_generic) {
         static VsrDevOnce p1, p2, p3, p4;
         if (d->Nk == 128) {
             const size_t l = (size_t)2 * (128 * HP + HP * 136) * es;
@@ -956,7 +956,7 @@ int vsr_window_attention_bwd(const VsrAttnDesc* d, const void* qkv, const float*
     if (d->Nq % qc != 0) return VSR_ERR_UNSUPPORTED;
     const size_t lds2 = ((size_t)2 * qc * HP + (size_t)2 * HP * (qc + 8)) * es + (size_t)2 * qc * 4;
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return VSR_ERR_UNSUPPORTED;
-    if (d->Nq == d->Nk && (d->Nk == 128 || d->Nk == 64) && !getenv("VSRLAB_AMD_ATTN_GENERIC")) {
+    if (d->Nq == d->Nk && (d->Nk == 128 || d->Nk == 64) && !vsr_env().attn_generic) {
         static VsrDevOnce p1, p2, p3, p4, p5, p6, p7, p8;
         const int nn = d->Nk;
         const size_t lq = (size_t)2 * (2 * nn * HP + HP * (nn + 8)) * es;

@@ -536,8 +536,9 @@ class _CharbonnierFn(torch.autograd.Function):
         lib = _lib.load()
         x32, y32 = _f32c(x), _f32c(y)
         dx = torch.empty_like(x32)
-        loss = torch.zeros((), dtype=torch.float32, device=x.device)
-        _lib.check(lib.vsr_charbonnier_fwd_bwd(_ptr(x32), _ptr(y32), _ptr(dx), _ptr(loss), x32.numel(), float(eps), _stream()),
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.vsr_charbonnier_scratch_floats(), dtype=torch.float32, device=x.device)
+        _lib.check(lib.vsr_charbonnier_fwd_bwd(_ptr(x32), _ptr(y32), _ptr(dx), _ptr(loss), _ptr(scratch), x32.numel(), float(eps), _stream()),
                    "charbonnier")
         ctx.save_for_backward(dx)
         return loss
@@ -675,25 +676,32 @@ def bce_with_logits_const(x: torch.Tensor, target: float) -> torch.Tensor:
 _MASK_BITS = {}
 
 
-def _packed_mask(m32: torch.Tensor):
-    """(bits, value) of a {0, value} attention mask (compute_mask's 0 / -100), or None if the mask has other values.
-    Cached per mask tensor: VRT builds one mask per stage shape (window_attention.py:61 is lru_cached)."""
-    key = (m32.data_ptr(), tuple(m32.shape), m32._version)
+def _packed_mask(mask: torch.Tensor):
+    """(m32, bits, value) for an attention mask: its contiguous fp32 form, and, for a {0, value} mask (compute_mask's 0 / -100)
+    whose row length is a multiple of 32, the bit-packed form + value (else bits = None).
+    Cached on the CALLER's tensor (identity, shape, dtype, version): ``TMSAG`` passes the lru-cached ``compute_mask`` tensor
+    itself, so every shifted block of every forward is a hit; keying on the fp32 copy (round 2) missed whenever the caller's mask
+    was not already contiguous fp32 and paid two host syncs + a re-pack per attention call.  A miss costs ONE host sync (the
+    mask value travels in the launch descriptor); at most 16 masks are kept."""
+    key = (mask.data_ptr(), tuple(mask.shape), mask.dtype, mask._version)
     hit = _MASK_BITS.get(key)
     if hit is None:
+        m32 = _f32c(mask)
         nW, Nm, _ = m32.shape
-        value = float(m32.min().item())                       # one host sync per distinct mask
-        ok = Nm % 32 == 0 and value != 0.0 and bool(((m32 == 0) | (m32 == value)).all().item())
-        if ok:
+        lo = m32.min()
+        ok_t = ((m32 == 0) | (m32 == lo)).all() & (lo != 0)
+        value, ok = (float(v) for v in torch.stack([lo, ok_t.to(lo.dtype)]).tolist())      # one transfer for both scalars
+        bits = None
+        if ok and Nm % 32 == 0:
             bits = torch.empty((nW, Nm, Nm // 32), dtype=torch.int32, device=m32.device)
             _lib.check(_lib.load().vsr_mask_pack(_ptr(m32), _ptr(bits), nW, Nm, _stream()), "mask_pack")
-            hit = (bits, value, m32)                           # keeps m32 alive: the key's data_ptr stays unique
         else:
-            hit = (None, 0.0, m32)
-        if len(_MASK_BITS) > 64:
+            value = 0.0
+        if len(_MASK_BITS) >= 16:
             _MASK_BITS.clear()
+        hit = (m32, bits, value, mask)                         # keeps `mask` alive: the key's data_ptr stays unique
         _MASK_BITS[key] = hit
-    return hit[0], hit[1]
+    return hit[0], hit[1], hit[2]
 
 
 class _WindowAttentionFn(torch.autograd.Function):
@@ -720,7 +728,7 @@ class _WindowAttentionFn(torch.autograd.Function):
         idx = index.contiguous()
         dense = torch.empty((heads, N, N), dtype=torch.float32, device=dev)
         _lib.check(lib.vsr_rpb_gather(_ptr(_f32c(table)), _ptr(idx), idx.shape[1], _ptr(dense), heads, N, _stream()), "rpb_gather")
-        m32 = _f32c(mask) if mask is not None else None
+        m32, bits, mval = _packed_mask(mask) if mask is not None else (None, None, 0.0)
         nW, Nm = (m32.shape[0], m32.shape[1]) if m32 is not None else (1, 0)
         if m32 is not None and (B % nW != 0 or Nm < N):
             raise ValueError("attention mask does not match the windows")
@@ -730,7 +738,6 @@ class _WindowAttentionFn(torch.autograd.Function):
             calls += [(qm, h2, 0, 0, h2, h2, 0, None),        # x1_aligned = attention(q2, k1, v1) -> tokens [0, N/2)
                       (qm, 0, h2, h2, h2, h2, 0, None)]       # x2_aligned = attention(q1, k2, v2) -> tokens [N/2, N)
         lses = []
-        bits, mval = _packed_mask(m32) if m32 is not None else (None, 0.0)
         for (t, q0, k0, o0, nq, nk, coff, bias) in calls:
             packed = bits is not None and nq == nk and nq in (64, 128)
             d = AttnDesc(B, N, heads, hd, q0, k0, o0, nq, nk, Cout, coff, nW, Nm, float(scale), dtype, int(packed), mval)

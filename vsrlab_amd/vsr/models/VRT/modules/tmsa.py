@@ -75,7 +75,10 @@ class TMSAG(nn.Module):
         Dp = -(-D // window_size[0]) * window_size[0]
         Hp = -(-H // window_size[1]) * window_size[1]
         Wp = -(-W // window_size[2]) * window_size[2]
-        attn_mask = compute_mask(Dp, Hp, Wp, window_size, shift_size, x.device).type_as(x)      # one mask for all shifted blocks (:191)
+        # one mask for all shifted blocks (:191).  The reference casts it `.type_as(x)`; the HIP attention reads masks as fp32
+        # (0 / -100 are exact in every dtype), and passing the lru-cached tensor itself lets functional._packed_mask hit its
+        # cache on every block of every forward (a fresh cast per call defeated it: two host syncs per attention call)
+        attn_mask = compute_mask(Dp, Hp, Wp, window_size, shift_size, x.device)
         for blk in self.blocks:
             x = blk(x, attn_mask)
         return x.reshape(B, D, H, W, -1).permute(0, 4, 1, 2, 3)
