@@ -866,3 +866,16 @@ def test_standalone_module_forwards_vs_oracle():
         assert tuple(y.shape) == (2, 2, 24, 40) and rel_err(y, ref) < 1e-3
     finally:
         del os.environ["VSRLAB_AMD_DTYPE"]
+
+
+def test_pipelined_tile_loop_of_the_persistent_conv_in_a_subprocess():
+    """VSRLAB_AMD_CONV_PIPE=1 selects the two-phase (software-pipelined) tile loop of the bias+skip persistent conv (off by
+    default: DESIGN 4.1).  The switch is read once per process, so the conv / ResidualConv parity tests run again in a child."""
+    _gpu()
+    import subprocess
+    import sys
+    env = dict(os.environ, VSRLAB_AMD_CONV_PIPE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "test_conv3x3_c64_fwd_dgrad_wgrad or test_residual_conv_module_fwd_bwd or test_ragged_sizes_and_single_frame"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -47,7 +47,7 @@ def main():
         launch(libs[i % len(libs)], i, 2)
     torch.cuda.synchronize()
     res = {n: {0: [], 1: []} for n in names}
-    clk = {n: [] for n in names}
+    clk = {n: {0: [], 1: []} for n in names}
     for r in range(rounds):
         for mode in (0, 1):
             for n, lib in zip(names, libs):
@@ -64,13 +64,14 @@ def main():
                     if lib.vsr_debug_read_clk(out.ctypes.data_as(P)) == 0:
                         o = out.reshape(256, 4).astype(np.float64)
                         ok = o[:, 1] > 0
-                        clk[n].append((float(np.median(o[ok, 0] / o[ok, 1] * 0.1)), float(np.median(o[ok, 0]))))
+                        clk[n][mode].append((float(np.median(o[ok, 0] / o[ok, 1] * 0.1)), float(np.median(o[ok, 0])), float(o[ok, 0].max())))
     for n in names:
         a0, a1 = np.array(res[n][0]), np.array(res[n][1])
         line = f"{n:32s} bias+relu med {np.median(a0):6.2f} min {a0.min():6.2f} | bias+skip med {np.median(a1):6.2f} min {a1.min():6.2f} us"
-        if clk[n]:
-            c = np.array(clk[n])
-            line += f" | clock {np.median(c[:, 0]):.3f} GHz, {np.median(c[:, 1]) / 1e3:.1f} k cycles per workgroup"
+        for mode, nm in ((0, "relu"), (1, "skip")):
+            if clk[n][mode]:
+                c = np.array(clk[n][mode])
+                line += f" | {nm}: clock {np.median(c[:, 0]):.3f} GHz, {np.median(c[:, 1]) / 1e3:.1f} k cycles per workgroup (median; slowest {np.median(c[:, 2]) / 1e3:.1f} k)"
         print(line, flush=True)
 
 

@@ -218,12 +218,14 @@ struct Ctx {
     hipStream_t st;
     int dtype;
     int lane;                   // 0: the caller's stream, 1: the helper stream (selects per-stream scratch)
+    int cu_div = 1;             // ConvArgs::cu_div of this context's persistent launches (2 inside the two-chain regions)
     mutable std::vector<VsrPackDesc>* batch = nullptr;      // while set, pack() collects descriptors for ONE multi-tensor launch
     void* at(size_t off) const { return ws + off; }
     const float* fat(size_t off) const { return reinterpret_cast<const float*>(ws + off); }
 
     ConvArgs base(int N, int H, int W) const {
         ConvArgs a = {};
+        a.cu_div = cu_div;
         a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1;
         a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C; a.dst_nstride = pm_image_elems(H, W, C);
         for (int s = 0; s < VSR_MAX_SRC; ++s) a.src_nstride[s] = pm_image_elems(H, W, C);
@@ -543,8 +545,8 @@ int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float
     {
         Fork f{st, nullptr};
         CK(f.begin());
-        const Ctx c1{p, ws, f.side(), p.dtype, 1};
-        CK(forward_chain(c, p, 0, lrs));
+        const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
+        CK(forward_chain(c0, p, 0, lrs));
         CK(forward_chain(c1, p, 1, lrs));
         CK(f.end());
     }
@@ -806,8 +808,8 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
     CK(f.begin());
-    const Ctx c1{p, ws, f.side(), p.dtype, 1};
-    CK(backward_chain(c, p, 1, lrs, g));
+    const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
+    CK(backward_chain(c0, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
     CK(f.end());
     if (dlrs) {   // part 2: the stems' LR channels (conv.py:97 on cat([lr_i, feat])), both directions, every frame
