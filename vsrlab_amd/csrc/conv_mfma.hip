@@ -28,14 +28,19 @@ constexpr int RW = 2;           // rows per wave
 constexpr int TH = 4 * RW;      // tile height
 constexpr int NTHREADS = 256;
 
+// 8-channel chunks in registers are NATIVE vectors: arrays of HIP's uint4 class (the weight-slab prefetch registers) were
+// not promoted to registers by hipcc and went through scratch memory in every instantiation of this kernel (r03: 469 scratch
+// instructions in this file).
+typedef __attribute__((ext_vector_type(4))) unsigned cu32x4_t;
+typedef __attribute__((ext_vector_type(8))) unsigned cu32x8_t;
 template <typename T> struct Elt;
 template <> struct Elt<bf16_t> {
     static constexpr int CHB = 16;                 // bytes per 8-channel chunk
     typedef bf16x8_t frag_t;
-    typedef uint4 chunk_t;
+    typedef cu32x4_t chunk_t;
 };
 struct f32x8_t { float v[8]; };
-struct chunk32_t { uint4 a, b; };
+typedef cu32x8_t chunk32_t;
 template <> struct Elt<float> {
     static constexpr int CHB = 32;
     typedef f32x8_t frag_t;
@@ -63,22 +68,17 @@ template <int CP> __device__ __forceinline__ int swz(int p, int c) {
 }
 
 template <typename T> __device__ __forceinline__ typename Elt<T>::chunk_t zero_chunk();
-template <> __device__ __forceinline__ uint4 zero_chunk<bf16_t>() { return make_uint4(0, 0, 0, 0); }
-template <> __device__ __forceinline__ chunk32_t zero_chunk<float>() {
-    chunk32_t z; z.a = make_uint4(0, 0, 0, 0); z.b = z.a; return z;
-}
+template <> __device__ __forceinline__ cu32x4_t zero_chunk<bf16_t>() { return cu32x4_t{0u, 0u, 0u, 0u}; }
+template <> __device__ __forceinline__ chunk32_t zero_chunk<float>() { return chunk32_t{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; }
 
-__device__ __forceinline__ uint4 make_chunk3(float a, float b, float c, bf16_t*) {
-    union { bf16_t h[8]; uint4 u; } t;
-    t.u = make_uint4(0, 0, 0, 0);
+__device__ __forceinline__ cu32x4_t make_chunk3(float a, float b, float c, bf16_t*) {
+    union { bf16_t h[8]; cu32x4_t u; } t;
+    t.u = cu32x4_t{0u, 0u, 0u, 0u};
     t.h[0] = (bf16_t)a; t.h[1] = (bf16_t)b; t.h[2] = (bf16_t)c;
     return t.u;
 }
 __device__ __forceinline__ chunk32_t make_chunk3(float a, float b, float c, float*) {
-    chunk32_t t;
-    t.a = make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), 0);
-    t.b = make_uint4(0, 0, 0, 0);
-    return t;
+    return chunk32_t{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), 0u, 0u, 0u, 0u, 0u};
 }
 
 __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
@@ -103,6 +103,14 @@ __device__ __forceinline__ void bil4(int d, int in_size, int& i0, int& i1, float
     l1 = s - (float)i0;
 }
 
+#ifndef VSR_CONV_ROW_STAGES
+#define VSR_CONV_ROW_STAGES 0      // r03: the row-stage form measured SLOWER (SPyNet 7x7 layers 13.7 vs 7.5 ms/step): kept for reference, off
+#endif
+// taps per weight stage: a whole kernel row for the single-source 7x7 layers whose tile + 7 slabs fit (<= 150 KB), else 1
+template <int KS, int NSRC> constexpr int conv_taps_per_stage(int tile_bytes, int slab_bytes) {
+    return (VSR_CONV_ROW_STAGES && KS == 7 && NSRC == 1 && tile_bytes + 7 * slab_bytes <= 150 * 1024) ? 7 : 1;
+}
+
 template <typename T, int KS, int NSRC, int CA, int CB, bool LASTPLANAR, int COUT, int EPI>
 __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2;
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int KK = KS * KS;
     constexpr int TILE_BYTES = NPIX * (CMAX / 8) * CHB;
     constexpr int SLAB_BYTES = COUT * (CMAX / 8) * CHB;
+    constexpr int TPS = conv_taps_per_stage<KS, NSRC>(TILE_BYTES, SLAB_BYTES);
     typedef typename Elt<T>::chunk_t chunk_t;
     typedef typename Elt<T>::frag_t frag_t;
 
@@ -193,6 +202,76 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
             constexpr int dummy2 = 0; (void)dummy2;
             const int SLAB_CHUNKS = COUT * CP;
             constexpr int MAXPT = (COUT * (CMAX / 8) + NTHREADS - 1) / NTHREADS;   // chunks per thread
+            if constexpr (TPS > 1) {
+                // 7x7 kernels (SPyNet): a STAGE = one kernel row of 7 taps.  The row's seven weight slabs sit in one LDS buffer; the
+                // next row's slabs are requested into registers before the row's MFMAs and written behind them: two barriers
+                // per 7 taps instead of two per tap (r03: the per-tap form ran the SPyNet layers at 0.54-0.64 PFLOP/s).
+                constexpr int NST = KK / TPS;
+                static_assert(KK % TPS == 0, "whole stages");
+                chunk_t wreg[TPS][MAXPT];
+#pragma unroll
+                for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+                    for (int i = 0; i < MAXPT; ++i) {
+                        const int idx = tid + i * NTHREADS;
+                        if (idx < SLAB_CHUNKS) wreg[tt][i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)tt * SLAB_CHUNKS + idx) * 8);
+                    }
+                for (int st = 0; st < NST; ++st) {
+                    if (st > 0) __syncthreads();                      // every wave has finished reading the previous row's slabs
+#pragma unroll
+                    for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+                        for (int i = 0; i < MAXPT; ++i) {
+                            const int idx = tid + i * NTHREADS;
+                            if (idx < SLAB_CHUNKS) {
+                                const int r = idx / CP, c = idx - r * CP;
+                                int sc;
+                                if (CP == 8) sc = swz<8>(r, c); else if (CP == 4) sc = swz<4>(r, c); else sc = swz<2>(r, c);
+                                *reinterpret_cast<chunk_t*>(lds_w + tt * SLAB_BYTES + (r * CP + sc) * CHB) = wreg[tt][i];
+                            }
+                        }
+                    __syncthreads();
+                    if (st + 1 < NST) {
+#pragma unroll
+                        for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+                            for (int i = 0; i < MAXPT; ++i) {
+                                const int idx = tid + i * NTHREADS;
+                                if (idx < SLAB_CHUNKS)
+                                    wreg[tt][i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)((st + 1) * TPS + tt) * SLAB_CHUNKS + idx) * 8);
+                            }
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < TPS; ++tt) {
+                        const int ky = st, kx = tt;                  // TPS == KS: stage = kernel row
+                        const char* wbuf = lds_w + tt * SLAB_BYTES;
+#pragma unroll
+                        for (int ks = 0; ks < C / 16; ++ks) {
+                            const int ch = 2 * ks + h;
+                            frag_t af[NCB], bf[RW];
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb) {
+                                const int r = cb * 32 + l31;
+                                int sc;
+                                if (CP == 8) sc = swz<8>(r, ch); else if (CP == 4) sc = swz<4>(r, ch); else sc = swz<2>(r, ch);
+                                af[cb] = lds_frag<T>(wbuf + (r * CP + sc) * CHB);
+                            }
+#pragma unroll
+                            for (int rw = 0; rw < RW; ++rw) {
+                                const int p = (wave * RW + rw + ky) * TWH + l31 + kx;
+                                int sc;
+                                if (CP == 8) sc = swz<8>(p, ch); else if (CP == 4) sc = swz<4>(p, ch); else sc = swz<2>(p, ch);
+                                bf[rw] = lds_frag<T>(lds_in + (p * CP + sc) * CHB);
+                            }
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                                for (int rw = 0; rw < RW; ++rw) mma(acc[cb][rw], af[cb], bf[rw]);
+                        }
+                    }
+                }
+                __syncthreads();
+            } else {
             chunk_t wreg[MAXPT];
             // tap 0 slab
 #pragma unroll
@@ -262,6 +341,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                 __syncthreads();
             }
         }
+            }   // TPS == 1
         woff += (long long)KK * COUT * C;
     }
 
@@ -345,7 +425,8 @@ int launch_inst(const ConvArgs& a, hipStream_t st) {
     constexpr int TWH = TW + KS - 1, THH = TH + KS - 1;
     constexpr int CMAX = CA > CB ? CA : CB;
     constexpr int CHB = Elt<T>::CHB;
-    constexpr int LDS = THH * TWH * (CMAX / 8) * CHB + 2 * COUT * (CMAX / 8) * CHB;
+    constexpr int TPS = conv_taps_per_stage<KS, NSRC>(THH * TWH * (CMAX / 8) * CHB, COUT * (CMAX / 8) * CHB);
+    constexpr int LDS = THH * TWH * (CMAX / 8) * CHB + (TPS > 1 ? TPS : 2) * COUT * (CMAX / 8) * CHB;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS of a CU");
     auto kern = conv_mfma_kernel<T, KS, NSRC, CA, CB, LP, COUT, EPI>;
     static VsrDevOnce once;
