@@ -1,0 +1,16 @@
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r3final
+mkdir -p $O
+timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -1 $O/bench_default.json | cut -c1-600 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace2s -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/trace2s.log 2>&1 &&
+VSRLAB_AMD_SINGLE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1s -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/trace1s.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o rl -- python3 bench.py --roofline-only > $O/pmc_fetch.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o rl -- python3 bench.py --roofline-only > $O/pmc_write.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o rl -- python3 bench.py --roofline-only > $O/pmc_mfma.log 2>&1 &&
+timeout -k 10 200 python tools/ab_conv.py 5 libvsrlab_hip.so libvsrlab_hip_conv3x3_persist_abl0.so > $O/clock.log 2>&1 &&
+timeout -k 10 200 python tools/ab_wgrad.py 5 libvsrlab_hip.so libvsrlab_hip_wgrad_mfma_abl0.so > $O/clock_wgrad.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gan -o gan -- python3 tools/bench_gan.py 1 > $O/gan_prof.log 2>&1 &&
+timeout -k 10 200 python tools/bench_gan.py 3 > $O/gan.log 2>&1; tail -1 $O/gan.log
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
+ls $O

@@ -61,9 +61,11 @@ def main():
     # the kernel, median over workgroups; MI355X_MICROARCH "DVFS give-back" item 6), same box and call as the traces ----
     try:
         import re
-        m = re.findall(r"clock ([0-9.]+) GHz", open(os.path.join(src, "clock.log")).read())
-        if m:
-            out["in_kernel_clock_GHz"] = float(m[-1])
+        txt = open(os.path.join(src, "clock.log")).read()
+        m = {k: re.findall(k + r": clock ([0-9.]+) GHz", txt) for k in ("relu", "skip")}
+        if m["relu"] and m["skip"]:
+            out["in_kernel_clock_GHz_by_variant"] = {k: float(v[-1]) for k, v in m.items()}
+            out["in_kernel_clock_GHz"] = round(0.5 * (float(m["relu"][-1]) + float(m["skip"][-1])), 3)      # the leg alternates the two
     except OSError:
         pass
     # ---- roofline leg: its 48 timed launches are the last 48 persistent-conv rows of any trace of bench.py ----
@@ -105,7 +107,9 @@ def main():
     by = defaultdict(list)
     for r in step:
         gx = int(r["Grid_Size_X"])
-        by[(r["Kernel_Name"].split("kernel")[1].split("(")[0], gx)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        name = r["Kernel_Name"].split("kernel")[1].split("(")[0]             # "<ACT, RES, MASK[, PIPE]>"
+        name = "<" + ", ".join(x.strip() for x in name.strip("<>").split(",")[:3]) + ">"
+        by[(name, gx)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     # trunk-shape launches only (grid = 256 CUs x 512 threads over a 540x960 image is indistinguishable by grid size from
     # the HR launches, so they are separated by duration: a 540p launch moves 133-199 MB, the HR ones 4-16x that)
     alg = {"<1, false, 0>": 2 * 64 * P540 * 2, "<0, true, 0>": 3 * 64 * P540 * 2, "<0, false, 3>": 2 * 64 * P540 * 2 + 4.2e6}
