@@ -184,6 +184,16 @@ int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wp
 int vsr_conv_layer_fwd(int dtype, int ks, const void* x_pm, int cin_pm, const float* lr_planar, const float* w,
                        const float* b, int cin_real, int cout_real, void* wpack, void* y_pm, int cd, float* y_planar,
                        int act, float slope, int pixel_shuffle, int N, int H, int W, void* stream);
+/* Backward of ONE layer of vsr_conv_layer_fwd (same shapes and argument meaning; the reference's ConvReLU / ResidualBlock stem /
+ * PixelShufflePack / SpynetModule layers are ordinary autograd modules: core/modules/conv.py:15-22,94-103, upsampling.py:4-12,
+ * spynet.py:13-21).  y_pm / y_planar: the forward's OUTPUT (source of the activation mask; may be NULL for act == 0);
+ * dy_pm / dy_planar: its cotangent, same layout.  Outputs (each may be NULL = not needed): dx_pm (layout of x_pm), dlr_planar
+ * (N,3,H,W) fp32, gw (OIHW fp32, overwritten), gb (overwritten).  scratch: vsr_conv_layer_bwd_scratch_bytes() bytes.        */
+size_t vsr_conv_layer_bwd_scratch_bytes(int dtype, int N, int H, int W, int pixel_shuffle);
+int vsr_conv_layer_bwd(int dtype, int ks, const void* x_pm, int cin_pm, const float* lr_planar, const float* w, int cin_real,
+                       int cout_real, const void* y_pm, const float* y_planar, const void* dy_pm, const float* dy_planar, int cd,
+                       int act, float slope, int pixel_shuffle, void* dx_pm, float* dlr_planar, float* gw, float* gb,
+                       void* scratch, size_t scratch_bytes, int N, int H, int W, void* stream);
 /* gw (64,64,3,3) and gb (64) fp32, overwritten.  slab: fp32 scratch of
  * vsr_conv3x3_c64_wgrad_slab_floats() floats.                                                */
 size_t vsr_conv3x3_c64_wgrad_slab_floats(void);

@@ -59,6 +59,9 @@ _SIGNATURES = {
     "vsr_conv3x3_c64_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_dgrad": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv_layer_fwd": (c_int, [c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
+    "vsr_conv_layer_bwd_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "vsr_conv_layer_bwd": (c_int, [c_int, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P,
+                                   _P, c_size_t, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_wgrad_slab_floats": (c_size_t, []),
     "vsr_conv3x3_c64_wgrad": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vsr_charbonnier_scratch_floats": (c_size_t, []),

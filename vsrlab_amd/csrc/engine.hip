@@ -1228,6 +1228,169 @@ int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wp
     return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
 }
 
+/* Backward of ONE conv layer of vsr_conv_layer_fwd (same shapes, same argument meaning): the reference's building blocks are ordinary
+ * autograd modules (core/modules/conv.py:15-22,94-103, upsampling.py:4-12, spynet.py:13-21), so each layer needs its data gradient,
+ * weight gradient and bias gradient on its own.  Every piece is a kernel the engines already run:
+ *   dyM = dy * act'(y)           (mask_pm / spynet_dres; act'(y) from the layer's stored OUTPUT y: ReLU / LeakyReLU keep the sign)
+ *   dx  = conv(dyM, flipped W)   (the forward kernels on weights packed with mode 1; pixel-shuffle: four phase launches)
+ *   dlr = the stems' 3 planar LR channels (64 -> 3 planar kernel)
+ *   gw, gb = wgrad(x, dyM)       (producer/consumer kernel for 3x3 64->64, generic kernel otherwise; reduced in a fixed order)
+ * x_pm / lr_planar / y_* as given to / returned by the forward; dy_* has y's layout.  dx_pm, dlr_planar, gw, gb may be NULL (not
+ * needed); gw / gb are OVERWRITTEN.  scratch: vsr_conv_layer_bwd_scratch_bytes(...) bytes.                                         */
+size_t vsr_conv_layer_bwd_scratch_bytes(int dtype, int N, int H, int W, int pixel_shuffle) {
+    if (bad_dtype(dtype) || bad_dims(N, H, W)) return 0;
+    const size_t es = esize(dtype);
+    const int s = pixel_shuffle ? 2 : 1;
+    int cp3, xp3, stride3;
+    vsr_wgrad_slab_dims(3, 64, 64, &cp3, &xp3, &stride3);
+    return (size_t)49 * 64 * 64 * 4 * es + (size_t)N * pm_image_elems(s * H, s * W, C) * es + (size_t)VSR_WGRAD_NWG * stride3 * 4 + 1024;
+}
+
+int vsr_conv_layer_bwd(int dtype, int ks, const void* x_pm, int cin_pm, const float* lr_planar, const float* w, int cin_real, int cout_real,
+                       const void* y_pm, const float* y_planar, const void* dy_pm, const float* dy_planar, int cd, int act, float slope,
+                       int pixel_shuffle, void* dx_pm, float* dlr_planar, float* gw, float* gb, void* scratch, size_t scratch_bytes,
+                       int N, int H, int W, void* stream) {
+    if (bad_dtype(dtype) || !w || !scratch || bad_dims(N, H, W) || (!x_pm && !lr_planar) || (!dy_pm && !dy_planar) || act < ACT_NONE || act > ACT_LEAKY)
+        return VSR_ERR_BADARG;
+    if (act != ACT_NONE && !(dy_pm ? y_pm != nullptr : y_planar != nullptr)) return VSR_ERR_BADARG;     // the mask needs the layer's output
+    if (scratch_bytes < vsr_conv_layer_bwd_scratch_bytes(dtype, N, H, W, pixel_shuffle)) return VSR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = esize(dtype);
+    char* wp = (char*)scratch;
+    char* dym = wp + (size_t)49 * 64 * 64 * 4 * es;
+    const int sps = pixel_shuffle ? 2 : 1;
+    float* slab = reinterpret_cast<float*>(dym + (((size_t)N * pm_image_elems(sps * H, sps * W, C) * es + 255) & ~(size_t)255));
+    const float mslope = act == ACT_LEAKY ? vsr_slope(slope) : 0.f;
+
+    // one weight-gradient launch + its reduction (gw / gb overwritten on the first call of a layer, accumulated by later ones)
+    auto wgrad = [&](int wks, int cx, bool xp, int cout, WgradArgs& a, int co_real, int ci_real, int I_total, int i_off, int o_mul, int o_add,
+                     float* gbias, int accumulate) -> int {
+        int cp, xpd, stride;
+        vsr_wgrad_slab_dims(wks, cx, cout, &cp, &xpd, &stride);
+        a.slab = slab; a.slab_stride = stride;
+        int cp3, xp3, stride3;
+        vsr_wgrad_slab_dims(3, 64, 64, &cp3, &xp3, &stride3);
+        const int tiles = a.N * cdiv(a.H, 8) * cdiv(a.W, 32);
+        const long long cap = (long long)VSR_WGRAD_NWG * stride3 / stride;
+        int nwg = tiles < VSR_WGRAD_NWG ? tiles : VSR_WGRAD_NWG;
+        if (nwg > cap) nwg = (int)cap;
+        if (nwg > 1) nwg &= ~1;
+        int nslabs = 0;
+        CK(vsr_launch_wgrad(dtype, wks, cx, xp, cout, false, a, nwg, &nslabs, st));
+        return vsr_launch_wgrad_reduce(slab, nslabs, wks, cx, cout, co_real, ci_real, gw, I_total, i_off, o_mul, o_add, gbias, accumulate, st);
+    };
+
+    if (!dy_pm) {   // planar output: the 16 -> 2 SPyNet layer.  dyM as a 16-channel pixel-major tensor
+        if (ks != 7 || cout_real != 2 || cin_pm != 16 || cin_real != 16 || !x_pm || pixel_shuffle) return VSR_ERR_UNSUPPORTED;
+        if (act == ACT_RELU) CK(vsr_launch_spynet_dres(dtype, dy_planar, y_planar, dym, N, H, W, st));
+        else if (act == ACT_NONE) CK(vsr_launch_planar_to_pm(dtype, dy_planar, dym, N, 2, H, W, 16, st));
+        else return VSR_ERR_UNSUPPORTED;
+    } else if (act != ACT_NONE) {
+        const int cdy = pixel_shuffle ? C : cd;
+        CK(vsr_launch_mask_pm(dtype, dy_pm, y_pm, dym, mslope, (long long)N * pm_image_elems(sps * H, sps * W, cdy), st));
+    }
+    const void* dyM = (!dy_pm || act != ACT_NONE) ? (const void*)dym : dy_pm;
+
+    if (lr_planar) {                                       // stems: cat([lr(3), feat(64)]) or lr alone  (conv.py:97)
+        if (ks != 3 || cout_real != C || cd != C || pixel_shuffle) return VSR_ERR_UNSUPPORTED;
+        const bool cat = x_pm != nullptr;
+        if ((cat && (cin_pm != C || cin_real != C + 3)) || (!cat && cin_real != 3)) return VSR_ERR_UNSUPPORTED;
+        const int I_total = cat ? C + 3 : 3;
+        if (cat && dx_pm) {
+            CK(vsr_launch_pack_weights(dtype, w, wp, 9, C, C, C, C, I_total, 3, 1, 0, 1, st));
+            ConvArgs a = plain64(dyM, wp, nullptr, dx_pm, N, H, W);
+            CK(vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st));
+        }
+        if (dlr_planar) {
+            CK(vsr_launch_pack_weights(dtype, w, wp, 9, 32, C, 3, C, I_total, 0, 1, 0, 1, st));
+            ConvArgs a = plain64(dyM, wp, nullptr, dlr_planar, N, H, W);
+            a.cout_real = 3; a.dst_nstride = (long long)3 * H * W;
+            CK(vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, st));
+        }
+        if (gw) {
+            WgradArgs a = wg_base(N, H, W);
+            a.x[0] = lr_planar; a.x_nstride = (long long)3 * H * W; a.dy[0] = dyM;
+            CK(wgrad(3, 16, true, 64, a, C, 3, I_total, 0, 1, 0, gb, 0));
+            if (cat) {
+                WgradArgs b2 = wg_base(N, H, W);
+                b2.x[0] = x_pm; b2.dy[0] = dyM;
+                CK(wgrad(3, 64, false, 64, b2, C, C, I_total, 3, 1, 0, nullptr, 0));
+            }
+        }
+        return VSR_OK;
+    }
+    if (ks == 3 || ks == 1) {
+        if (cin_pm != C || cin_real != C || !x_pm) return VSR_ERR_UNSUPPORTED;
+        if (pixel_shuffle) {                               // conv3x3 64 -> 256 + PixelShuffle(2)  (upsampling.py:10-12)
+            if (ks != 3 || cout_real != 4 * C || cd != C || act != ACT_NONE) return VSR_ERR_UNSUPPORTED;
+            if (dx_pm) {
+                for (int z = 0; z < 4; ++z) CK(vsr_launch_pack_weights(dtype, w, wp + (size_t)z * 9 * C * C * es, 9, C, C, C, C, C, 0, 4, z, 1, st));
+                if (dtype == VSR_BF16) {
+                    for (int z = 0; z < 4; ++z) {          // phase z reads phase z-1's partial sum as its residual, in place
+                        ConvArgs a = plain64(dyM, wp + (size_t)z * 9 * C * C * es, nullptr, dx_pm, N, H, W);
+                        a.in_step = 2; a.Hs = 2 * H; a.Ws = 2 * W; a.src_oy[0] = z >> 1; a.src_ox[0] = z & 1;
+                        a.src_nstride[0] = pm_image_elems(2 * H, 2 * W, C);
+                        a.res[0] = z > 0 ? dx_pm : nullptr;
+                        CK(vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st));
+                    }
+                } else {
+                    ConvArgs a = plain64(dyM, wp, nullptr, dx_pm, N, H, W);
+                    a.in_step = 2; a.Hs = 2 * H; a.Ws = 2 * W;
+                    for (int q = 0; q < 4; ++q) { a.src[q] = dyM; a.src_oy[q] = q >> 1; a.src_ox[q] = q & 1; a.src_nstride[q] = pm_image_elems(2 * H, 2 * W, C); }
+                    CK(vsr_launch_conv(dtype, 3, 4, 64, 64, 0, 64, EPI_NHWC, a, st));
+                }
+            }
+            if (gw)
+                for (int z = 0; z < 4; ++z) {
+                    WgradArgs a = wg_base(N, H, W);
+                    a.x[0] = x_pm; a.dy[0] = dyM;
+                    a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = 2 * H; a.Wy = 2 * W; a.dy_nstride = pm_image_elems(2 * H, 2 * W, C);
+                    CK(wgrad(3, 64, false, 64, a, C, C, C, 0, 4, z, gb, 0));
+                }
+            return VSR_OK;
+        }
+        if (cout_real != C || cd != C) return VSR_ERR_UNSUPPORTED;
+        if (dx_pm) {
+            CK(vsr_launch_pack_weights(dtype, w, wp, ks * ks, C, C, C, C, C, 0, 1, 0, 1, st));
+            ConvArgs a = plain64(dyM, wp, nullptr, dx_pm, N, H, W);
+            CK(vsr_launch_conv(dtype, ks, 1, 64, 64, 0, 64, EPI_NHWC, a, st));
+        }
+        if (gw) {
+            WgradArgs a = wg_base(N, H, W);
+            a.x[0] = x_pm; a.dy[0] = dyM;
+            CK(wgrad(ks, 64, false, 64, a, C, C, C, 0, 1, 0, gb, 0));
+        }
+        return VSR_OK;
+    }
+    if (ks != 7 || pixel_shuffle || !x_pm) return VSR_ERR_UNSUPPORTED;
+    for (int j = 0; j < NSPY; ++j) {                       // the SPyNet layer shapes (spynet.py:16-18), as spynet_backward runs them
+        if (cin_pm != SPY_CIP[j] || cout_real != SPY_CO[j] || cin_real != SPY_CI[j]) continue;
+        const int CI = SPY_CIP[j], CO = SPY_DK[j];
+        if (j < NSPY - 1 && cd != SPY_CD[j]) return VSR_ERR_BADARG;
+        if (gw) {
+            const int nhalf = (dtype == VSR_F32 && CI == 64) ? 2 : 1;          // fp32, 64 input channels: two 32-channel halves (LDS)
+            for (int hf = 0; hf < nhalf; ++hf) {
+                WgradArgs a = wg_base(N, H, W);
+                a.x[0] = x_pm; a.x_nstride = pm_image_elems(H, W, CI);
+                a.dy[0] = dyM; a.dy_nstride = pm_image_elems(H, W, CO);
+                const int cx = CI / nhalf;
+                if (nhalf == 2) { a.x_ctotal = CI; a.x_coff = hf * (cx / 8); }
+                CK(wgrad(7, cx, false, CO, a, SPY_CO[j], nhalf == 2 ? cx : SPY_CI[j], SPY_CI[j], hf * cx, 1, 0, hf == 0 ? gb : nullptr, 0));
+            }
+        }
+        if (dx_pm) {
+            CK(vsr_launch_pack_weights(dtype, w, wp, 49, SPY_DROWS[j], SPY_DK[j], SPY_CI[j], SPY_CO[j], SPY_CI[j], 0, 1, 0, 1, st));
+            ConvArgs a = {};
+            a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1; a.out_step = 1; a.Hd = H; a.Wd = W;
+            a.src[0] = dyM; a.src_nstride[0] = pm_image_elems(H, W, CO);
+            a.wpack = wp; a.dst[0] = dx_pm; a.CD = CI; a.cout_real = j == 0 ? 8 : CI; a.dst_nstride = pm_image_elems(H, W, CI);
+            CK(vsr_launch_conv(dtype, 7, 1, CO, CO, 0, SPY_DROWS[j], EPI_NHWC, a, st));
+        }
+        return VSR_OK;
+    }
+    return VSR_ERR_UNSUPPORTED;
+}
+
 /* One convolution layer on blocked pixel-major tensors, forward only: the building blocks the reference's modules expose
  * on their own (ConvReLU core/modules/conv.py:15-22, SpynetModule spynet.py:13-21, PixelShufflePack upsampling.py:4-12,
  * the stem of ResidualBlock conv.py:97).  w: fp32 OIHW (cout_real, cin_real [+3 for lr_planar], ks, ks); b: cout_real or NULL.

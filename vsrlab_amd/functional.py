@@ -790,14 +790,9 @@ def window_attention_core(qkv_self: torch.Tensor, qkv_mut: Optional[torch.Tensor
 
 
 # --------------------------------------------------------------------------------------------- #
-# single conv layers of the reference's building blocks, forward only (inference / composition of custom pipelines)
+# single conv layers of the reference's building blocks (ConvReLU, the ResidualBlock stem, PixelShufflePack, SpynetModule's
+# layers): forward vsr_conv_layer_fwd, backward vsr_conv_layer_bwd -- ordinary autograd modules, like the reference's
 # --------------------------------------------------------------------------------------------- #
-def _no_grad_only(what: str, *tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError(f"{what} is inference-only on the HIP path when called on its own (its backward runs inside the "
-                                  "BasicVSR / SPyNet engines): call it under torch.no_grad()")
-
-
 def conv_layer(x_pm: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0, slope: float = 0.1,
                lr_planar: Optional[torch.Tensor] = None, pixel_shuffle: bool = False, planar_out: bool = False,
                dtype: Optional[int] = None, hw: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
@@ -828,55 +823,107 @@ def conv_layer(x_pm: Optional[torch.Tensor], weight: torch.Tensor, bias: Optiona
     return y_pl if planar_out else y_pm
 
 
+class _ConvLayerFn(torch.autograd.Function):
+    """y = act(conv(x [, lr]) + b) [+ PixelShuffle(2)] on planar (N,C,H,W) tensors; x / lr may be None (stems).  Backward =
+    ``vsr_conv_layer_bwd``: data gradient(s), weight gradient, bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, lr, weight, bias, act, slope, pixel_shuffle, planar_out, dt):
+        cout, cin = weight.shape[:2]
+        ref = x if x is not None else lr
+        n, _, h, w = ref.shape
+        x_pm = None
+        if x is not None:
+            x_pm = to_pixel_major(x, dt, ((x.shape[1] + 15) // 16) * 16)
+        lr32 = None if lr is None else _f32c(lr)
+        y = conv_layer(x_pm, weight, bias, act=act, slope=slope, lr_planar=lr32, pixel_shuffle=pixel_shuffle, planar_out=planar_out,
+                       dtype=dt, hw=(n, h, w))
+        ctx.save_for_backward(x_pm, lr32, weight, y)
+        ctx.meta = (act, float(slope), bool(pixel_shuffle), bool(planar_out), dt, n, h, w, cin, cout, None if x is None else x.shape[1],
+                    x_pm.pm_w if x_pm is not None else None, bias is not None)
+        if planar_out:
+            return y
+        return from_pixel_major(y, 64 if pixel_shuffle else cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_pm, lr32, weight, y = ctx.saved_tensors
+        act, slope, ps, planar, dt, n, h, w, cin, cout, xc, xw, has_bias = ctx.meta
+        lib = _lib.load()
+        dev = dout.device
+        if x_pm is not None:
+            x_pm.pm_w = xw
+        need_x, need_lr, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        cd = 0 if planar else (64 if ps else max(16, cout))
+        dy_pm = dy_pl = y_pm = y_pl = None
+        if planar:
+            dy_pl, y_pl = _f32c(dout), y
+        else:
+            dy_pm = to_pixel_major(dout, dt, cd)
+            y_pm = y
+        dx_pm = None
+        if need_x and x_pm is not None:
+            dx_pm = torch.empty_like(x_pm)
+            dx_pm.pm_w = xw
+        dlr = torch.empty_like(lr32) if (need_lr and lr32 is not None) else None
+        gw = torch.empty(weight.shape, dtype=torch.float32, device=dev) if (need_w or need_b) else None
+        gb = torch.empty(cout, dtype=torch.float32, device=dev) if (need_b and has_bias) else None
+        nbytes = lib.vsr_conv_layer_bwd_scratch_bytes(dt, n, h, w, int(ps))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ks = weight.shape[2]
+        _lib.check(lib.vsr_conv_layer_bwd(dt, ks, _ptr(x_pm), 0 if x_pm is None else x_pm.shape[3] * 8, _ptr(lr32), _ptr(_f32c(weight)), cin, cout,
+                                          _ptr(y_pm), _ptr(y_pl), _ptr(dy_pm), _ptr(dy_pl), cd, act, slope, int(ps), _ptr(dx_pm), _ptr(dlr),
+                                          _ptr(gw), _ptr(gb), _ptr(scratch), nbytes, n, h, w, _stream()), "conv_layer_bwd")
+        dx = from_pixel_major(dx_pm, xc) if dx_pm is not None else None
+        return dx, dlr, (gw if need_w else None), gb, None, None, None, None, None
+
+
+def _conv_layer_autograd(x, lr, weight, bias, act, slope=0.1, pixel_shuffle=False, planar_out=False, compute_dtype=None):
+    return _ConvLayerFn.apply(x, lr, weight, bias, act, slope, pixel_shuffle, planar_out, resolve_dtype(compute_dtype))
+
+
 def conv_relu_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], compute_dtype: Optional[str] = None) -> torch.Tensor:
-    """ConvReLU.forward (core/modules/conv.py:15-22) for the SPyNet layer shapes (7x7) and 64 -> 64 (3x3 / 1x1)."""
+    """ConvReLU.forward (core/modules/conv.py:15-22) for the SPyNet layer shapes (7x7) and 64 -> 64 (3x3 / 1x1); differentiable."""
     _require_gpu(x)
-    _no_grad_only("ConvReLU", x, weight, bias)
-    dt = resolve_dtype(compute_dtype)
-    cout, cin = weight.shape[:2]
-    xp = to_pixel_major(x, dt, ((cin + 15) // 16) * 16)
-    if cout <= 4:
-        return conv_layer(xp, weight, bias, act=1, planar_out=True)
-    return from_pixel_major(conv_layer(xp, weight, bias, act=1), cout)
+    cout = weight.shape[0]
+    return _conv_layer_autograd(x, None, weight, bias, 1, planar_out=cout <= 4, compute_dtype=compute_dtype)
 
 
 def spynet_module_forward(x: torch.Tensor, params: Sequence[torch.Tensor], last_relu: bool = True,
                           compute_dtype: Optional[str] = None) -> torch.Tensor:
-    """SpynetModule.forward (spynet.py:13-21): (N,8,h,w) -> (N,2,h,w) through the five 7x7 layers."""
+    """SpynetModule.forward (spynet.py:13-21): (N,8,h,w) -> (N,2,h,w) through the five 7x7 layers; differentiable w.r.t. x and
+    the ten parameter tensors."""
     _require_gpu(x)
-    _no_grad_only("SpynetModule", x, *params)
     if x.shape[1] != 8 or len(params) != 10:
         raise ValueError("SpynetModule takes (N,8,h,w) and has 10 parameter tensors")
-    y = to_pixel_major(x, resolve_dtype(compute_dtype), 16)
+    y = x
     for j in range(4):
-        y = conv_layer(y, params[2 * j], params[2 * j + 1], act=1)
-    return conv_layer(y, params[8], params[9], act=1 if last_relu else 0, planar_out=True)
+        y = _conv_layer_autograd(y, None, params[2 * j], params[2 * j + 1], 1, compute_dtype=compute_dtype)
+    return _conv_layer_autograd(y, None, params[8], params[9], 1 if last_relu else 0, planar_out=True, compute_dtype=compute_dtype)
 
 
 def pixel_shuffle_pack_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], compute_dtype: Optional[str] = None):
-    """PixelShufflePack.forward (upsampling.py:10-12): conv3x3 64 -> 256 + PixelShuffle(2); the shuffle is the store pattern."""
+    """PixelShufflePack.forward (upsampling.py:10-12): conv3x3 64 -> 256 + PixelShuffle(2); the shuffle is the store pattern;
+    differentiable."""
     _require_gpu(x)
-    _no_grad_only("PixelShufflePack", x, weight, bias)
     if x.shape[1] != 64 or tuple(weight.shape) != (256, 64, 3, 3):
         raise NotImplementedError("the HIP PixelShufflePack is built for 64 -> 64 channels, scale 2 (the reference's use)")
-    return from_pixel_major(conv_layer(to_pixel_major(x, resolve_dtype(compute_dtype)), weight, bias, pixel_shuffle=True), 64)
+    return _conv_layer_autograd(x, None, weight, bias, 0, pixel_shuffle=True, compute_dtype=compute_dtype)
 
 
 def residual_block_forward(x: torch.Tensor, stem_w: torch.Tensor, stem_b: torch.Tensor, blocks: Sequence[Tuple[torch.Tensor, ...]],
                            compute_dtype: Optional[str] = None) -> torch.Tensor:
     """ResidualBlock.forward (core/modules/conv.py:94-103) on x = cat([lr(3), feat(64)]) (the trunks) or x = lr (the pre-clean
-    stack): conv3x3 + LeakyReLU(0.1), then the ResidualConv blocks ((w1, b1, w2, b2) each)."""
+    stack): conv3x3 + LeakyReLU(0.1), then the ResidualConv blocks ((w1, b1, w2, b2) each); differentiable (the stem through
+    vsr_conv_layer_bwd, the blocks through the ResidualConv function)."""
     _require_gpu(x)
-    _no_grad_only("ResidualBlock", x, stem_w, stem_b)
     n, cin, h, w = x.shape
-    dt = resolve_dtype(compute_dtype)
     if cin == 67:
-        y = conv_layer(to_pixel_major(x[:, 3:].contiguous(), dt), stem_w, stem_b, act=2, lr_planar=x[:, :3].contiguous())
+        y = _conv_layer_autograd(x[:, 3:].contiguous(), x[:, :3].contiguous(), stem_w, stem_b, 2, compute_dtype=compute_dtype)
     elif cin == 3:
-        y = conv_layer(None, stem_w, stem_b, act=2, lr_planar=x, dtype=dt, hw=(n, h, w))
+        y = _conv_layer_autograd(None, x, stem_w, stem_b, 2, compute_dtype=compute_dtype)
     else:
         raise NotImplementedError("the HIP ResidualBlock stem takes 3 (pre-clean) or 3 + 64 (trunk) input channels")
     for (w1, b1, w2, b2) in blocks:
-        a = conv3x3_c64(y, w1, b1, act=1)
-        y = conv3x3_c64(a, w2, b2, act=0, res_pm=y)
-    return from_pixel_major(y)
+        y = residual_conv(y, w1, b1, w2, b2, compute_dtype)
+    return y
