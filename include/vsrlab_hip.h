@@ -174,7 +174,7 @@ int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float
 int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm,
                           const void* res_pm, const void* aux_pm, int mask_mode, int N, int H,
                           int W, void* stream);
-/* One convolution layer, forward only, for the building blocks the reference's modules expose on their own: ConvReLU
+/* One convolution layer (forward; its backward is vsr_conv_layer_bwd below), for the building blocks the reference's modules expose on their own: ConvReLU
  * (core/modules/conv.py:15-22), SpynetModule (spynet.py:13-21), PixelShufflePack (upsampling.py:4-12), the stem of
  * ResidualBlock (conv.py:97).  w fp32 OIHW, b fp32 or NULL.
  *   ks 3 / 1: 64 -> 64 (pixel_shuffle != 0: 64 -> 256 written as (N,2H,2W,64));

@@ -3,7 +3,8 @@
 arguments, same parameter names (``conv.0.weight``, ``res_block.{i}.conv1.weight`` ...), so
 checkpoints load strictly.  Inside ``BasicVSR`` / ``Spynet`` / ``UNetDiscriminator`` the whole network runs in one engine
 call and these modules are its parameter containers; called on their own they dispatch to the per-layer kernels
-(``ResidualConv`` with its full backward; ``ConvReLU`` / ``ResidualBlock`` forward-only, i.e. under ``torch.no_grad()``)."""
+(all differentiable: ``ResidualConv`` through its fused forward/backward function, ``ConvReLU`` and the ``ResidualBlock`` stem through
+``vsr_conv_layer_fwd`` / ``vsr_conv_layer_bwd``)."""
 import torch
 import torch.nn as nn
 

@@ -1,7 +1,7 @@
 """``PixelShufflePack`` (vsrlab ``src/core/modules/upsampling.py:4-12``): conv3x3 C->4C then
 PixelShuffle(2), no activation.  On the HIP path the shuffle is the store pattern of the conv
 kernel (four sub-convolutions, one launch).  Inside ``BasicVSR`` it runs in the engine; called on its own it is one
-``vsr_conv_layer_fwd`` launch (forward-only)."""
+``vsr_conv_layer_fwd`` launch; backward = ``vsr_conv_layer_bwd`` (four phase data-gradient launches + four weight-gradient launches)."""
 import torch.nn as nn
 
 from ... import functional as VF
