@@ -377,3 +377,25 @@ def test_flat_grad_sync_gathers_foreign_gradients_before_the_exchange(tmp_path):
     port = 33500 + os.getpid() % 2000
     mp.spawn(_foreign_grad_worker, args=(2, port, out), nprocs=2, join=True)
     assert os.path.exists(out)
+
+
+def test_drop_path_is_the_references_stochastic_depth():
+    """TMSA(drop_path > 0) (tmsa.py:57,103,110): DropPath restated (stochastic_depth.py:4-23): same CPU-generator draw per sample,
+    kept samples scaled by 1 / keep_prob, identity in eval; TMSA / TMSAG accept the argument like the reference's."""
+    from vsrlab_amd.vsr.models.VRT.modules.tmsa import DropPath, TMSA, TMSAG
+    x = torch.randn(6, 3, 4, 5)
+    dp = DropPath(0.4)
+    dp.eval()
+    assert torch.equal(dp(x), x)
+    dp.train()
+    torch.manual_seed(11)
+    got = dp(x)
+    torch.manual_seed(11)
+    keep = 0.6
+    r = (keep + torch.rand((6, 1, 1, 1))).floor_()          # the reference's formula, verbatim semantics
+    assert torch.equal(got, x.div(keep) * r)
+    assert 0 < int(r.sum()) < 6                              # the seed drops some samples and keeps some
+    blk = TMSA(dim=24, input_resolution=(2, 8, 8), num_heads=2, window_size=(2, 8, 8), drop_path=0.25)
+    assert isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob == 0.25
+    grp = TMSAG(dim=24, input_resolution=(2, 8, 8), depth=2, num_heads=2, window_size=[2, 8, 8], drop_path=[0.0, 0.3])
+    assert isinstance(grp.blocks[0].drop_path, torch.nn.Identity) and grp.blocks[1].drop_path.drop_prob == 0.3

@@ -2,8 +2,8 @@
 HIP window attention inside, and its two containers ``TMSAG`` (``tmsa.py:126-202``: depth blocks, every second one
 shifted, one attention mask per call) and ``RTMSA`` (``tmsa.py:204-251``: residual TMSAG without mutual attention + a
 linear layer).  Same constructors, parameter names (``norm1``, ``attn.*``, ``norm2``, ``mlp.*``; ``blocks.{i}.*``;
-``residual_group.*``, ``linear.*``) and forwards.  ``drop_path`` > 0 (stochastic depth) is a training-time regulariser
-outside the hot path and is not offered."""
+``residual_group.*``, ``linear.*``) and forwards.  ``drop_path`` > 0 = stochastic depth (``DropPath`` below, ``stochastic_depth.py``:
+one per-sample Bernoulli scale of each residual branch in training, identity in eval)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -11,19 +11,35 @@ import torch.nn.functional as F
 from .window_attention import Mlp_GEGLU, WindowAttention, compute_mask, get_window_size, window_partition, window_reverse
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample (stochastic_depth.py:4-23): in training, a sample's residual branch is dropped with probability
+    ``drop_prob`` and the kept ones are scaled by 1 / (1 - drop_prob); identity in eval.  One Bernoulli draw per sample from the CPU
+    generator, exactly as the reference draws it (``torch.rand(shape)`` without a device), so a seeded run drops the same samples."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.drop_prob or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        draw = torch.rand((x.shape[0],) + (1,) * (x.ndim - 1))              # CPU generator, like the reference
+        kept = torch.floor(keep + draw).to(device=x.device, dtype=x.dtype)      # 1 with probability keep, else 0
+        return x.div(keep) * kept                                                 # the reference's operation order (bit-identical)
+
+
 class TMSA(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size=(6, 8, 8), shift_size=(0, 0, 0), mut_attn=True, mlp_ratio=2.,
                  qkv_bias=True, qk_scale=None, drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        if drop_path > 0.:
-            raise NotImplementedError("stochastic depth is not on the HIP path")
         self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
         self.window_size, self.shift_size = window_size, shift_size
         assert all(0 <= s < w for s, w in zip(shift_size, window_size)), "shift_size must be in range [0, window_size]"
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(dim, window_size=self.window_size, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
                                     mut_attn=mut_attn)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp_GEGLU(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
 
@@ -43,10 +59,10 @@ class TMSA(nn.Module):
         y = window_reverse(out.view(-1, *win, C), win, B, Dp, Hp, Wp)
         if shifted:
             y = torch.roll(y, shifts=tuple(shift), dims=(1, 2, 3))
-        return y[:, :D, :H, :W, :] if any(pad) else y
+        return self.drop_path(y[:, :D, :H, :W, :] if any(pad) else y)
 
     def forward_part2(self, x):
-        return self.mlp(self.norm2(x))
+        return self.drop_path(self.mlp(self.norm2(x)))
 
     def forward(self, x, mask_matrix):
         x = x + self.forward_part1(x, mask_matrix)
