@@ -897,3 +897,26 @@ def test_pipelined_tile_loop_of_the_persistent_conv_in_a_subprocess():
                         "test_conv3x3_c64_fwd_dgrad_wgrad or test_residual_conv_module_fwd_bwd or test_ragged_sizes_and_single_frame"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 41), (3, 37, 70), (4, 200, 330)])
+def test_spynet_7x7_layers_on_the_persistent_kernels(shape):
+    """The five SPyNet layer shapes (spynet.py:16-18) on the persistent 7x7 kernels (conv7x7_persist.hip: streamed / resident
+    weights, tap pairs for the 16-channel layers), bf16 build, through ConvReLU's per-op entry: against the same convolution of
+    the bf16-rounded operands in fp32 (torch on the GPU; what differs is the summation order and the output's rounding to bf16:
+    2^-8 relative), on ragged sizes from a single partial tile to several tiles per workgroup (4 x 200 x 330 = 1100 tiles on
+    256 workgroups: the weight ring wraps and both tile buffers are re-used), and bit-identical on a repeat."""
+    dev = _gpu()
+    from vsrlab_amd import functional as VF
+    n, h, w = shape
+    for j, (ci, co) in enumerate([(8, 32), (32, 64), (64, 32), (32, 16), (16, 2)]):
+        x = bf16_round(rand(300 + j, n, ci, h, w, lo=-1, hi=1)).to(dev)
+        wt = bf16_round(rand(310 + j, co, ci, 7, 7, lo=-1, hi=1) / (7.0 * ci ** 0.5)).to(dev)
+        b = rand(320 + j, co, lo=-0.5, hi=0.5).to(dev)
+        y = VF.conv_relu_forward(x, wt, b, compute_dtype="bf16")
+        ref = F.relu(F.conv2d(x, wt, b, padding=3))
+        assert tuple(y.shape) == tuple(ref.shape)
+        err = (y - ref).abs()
+        bound = ref.abs() * 2.0 ** -7 + 1e-3 if co > 4 else ref.abs() * 1e-4 + 1e-4     # the 2-channel layer stores fp32
+        assert bool((err <= bound).all()), (shape, ci, co, float(err.max()), float(ref.abs().max()))
+        assert torch.equal(y, VF.conv_relu_forward(x, wt, b, compute_dtype="bf16")), (shape, ci, co)
