@@ -230,6 +230,9 @@ def main():
     ap.add_argument("--dp", default="flat", choices=["flat", "ddp"],
                     help="N > 1: flat = one all-reduce over the gradient arena (vsrlab_amd.parallel.FlatGradSync); ddp = torch DistributedDataParallel")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel leg (for rocprofv3 PMC passes)")
+    ap.add_argument("--arena", default="full", choices=["full", "diet"],
+                    help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 131 GiB per clip, all-frames weight-gradient launches "
+                         "(the headline configuration); diet = 65 GiB per clip (per-frame weight gradients, HR activations recomputed)")
     args = ap.parse_args()
     if args.optimizer == "torch" and args.dp == "flat":
         args.dp = "ddp"
@@ -257,6 +260,8 @@ def main():
 
     from vsrlab_amd.core.losses import CharbonnierLoss
     from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+    from vsrlab_amd import functional as VF
+    VF.set_arena_mode(args.arena)
 
     torch.manual_seed(0)
     model = BasicVSR(64, args.res_blocks, 4, False, False).to(dev)
@@ -327,7 +332,8 @@ def main():
                        "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "res_blocks": args.res_blocks,
                        "parallelism": (f"dp{world} (clip-level; " + ("one RCCL all-reduce of the flat gradient arena per step)" if sync is not None
                                                                         else "DDP grad all-reduce over RCCL)")) if world > 1 else "single GPU",
-                       "optimizer_in_timed_region": "fused clip_grad_norm(1)+Adam (HIP)" if args.optimizer == "fused" else "torch.optim.Adam"},
+                       "optimizer_in_timed_region": "fused clip_grad_norm(1)+Adam (HIP)" if args.optimizer == "fused" else "torch.optim.Adam",
+                       "arena": args.arena, "peak_hbm_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
             "loss": round(loss_val, 6), "tree": tree_id(),
         }
         bpf = algorithmic_bytes_per_frame(h, w, t, args.res_blocks, 2 if args.dtype == "bf16" else 4)

@@ -55,6 +55,12 @@ typedef struct VsrBasicVSRDesc {
     int res_blocks;
     int upscale;
     int dtype;           /* VSR_DT_* of the internal activations */
+    int arena_mode;      /* training workspace (ABI 3): 0 = every activation and activation gradient of the clip stays in the
+                          * workspace and the weight gradients run as all-frames launches (fastest; 127 GiB at BASELINE config 2);
+                          * 1 = "diet": the trunks' activation gradients live in a two-block ring and each frame's weight gradients
+                          * are launched behind its data gradients; the two HR tensors of a frame (upsample.1 / conv_last.0 outputs)
+                          * are recomputed in the backward (63 GiB at config 2, two clips per 288 GB GPU; same results up to the
+                          * summation order of the weight gradients over frames).  Ignored by inference (need_backward = 0).     */
 } VsrBasicVSRDesc;
 
 /* Number of parameter tensors.  Order, by the reference module's state_dict KEYS (state_dict()

@@ -46,7 +46,7 @@ DTYPES = ["fp32", "bf16"]
 def test_library_loaded_and_abi():
     import vsrlab_amd
     lib = vsrlab_amd._lib.load()
-    assert lib.vsr_abi_version() == 2
+    assert lib.vsr_abi_version() == 3
     _gpu()
 
 
@@ -920,3 +920,42 @@ def test_spynet_7x7_layers_on_the_persistent_kernels(shape):
         bound = ref.abs() * 2.0 ** -7 + 1e-3 if co > 4 else ref.abs() * 1e-4 + 1e-4     # the 2-channel layer stores fp32
         assert bool((err <= bound).all()), (shape, ci, co, float(err.max()), float(ref.abs().max()))
         assert torch.equal(y, VF.conv_relu_forward(x, wt, b, compute_dtype="bf16")), (shape, ci, co)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_diet_arena_matches_the_full_arena(dtype):
+    """VsrBasicVSRDesc.arena_mode = 1 ("diet", functional.set_arena_mode): the trunks' activation gradients in a two-block ring with
+    each frame's weight gradients launched behind its data gradients, U0 / U1 / C0 of the reconstruction recomputed in the
+    backward.  Same kernels on the same operands, so sr and every data-path tensor are bit-identical; the weight gradients differ
+    only in the order the frames are summed (fp32 accumulation: 1e-5 relative L2 per tensor; the two modes are compared with
+    each other here, the diet mode with the oracle / goldens by the next test).  Frozen flow and train_flow, ragged size."""
+    dev = _gpu()
+    from vsrlab_amd import functional as VF
+    for (shape, blocks, train_flow) in [((1, 5, 3, 40, 72), 4, False), ((2, 3, 3, 13, 37), 2, True)]:
+        out = {}
+        for mode in ("full", "diet"):
+            VF.set_arena_mode(mode)
+            try:
+                _, _, _, sr, grads = _run_basicvsr(dtype, 64, blocks, shape, 91, 92, dev, train_flow=train_flow)
+            finally:
+                VF.set_arena_mode(None)
+            out[mode] = (sr, grads)
+        assert torch.equal(out["full"][0], out["diet"][0]), (shape, "sr")
+        assert set(out["full"][1]) == set(out["diet"][1])
+        for k, v in out["full"][1].items():
+            assert rel_l2(out["diet"][1][k], v) < 1e-5, (shape, k, rel_l2(out["diet"][1][k], v))
+
+
+def test_parity_suite_on_the_diet_arena_in_a_subprocess():
+    """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
+    is process-wide, so they run in a child, like the pipelined-conv A/B above."""
+    _gpu()
+    import subprocess
+    import sys
+    env = dict(os.environ, VSRLAB_AMD_ARENA="diet")
+    sel = ("test_basicvsr_end_to_end_vs_golden or test_basicvsr_train_flow_vs_golden or test_basicvsr_input_gradient_vs_golden or "
+           "test_ragged_sizes_and_single_frame or test_far_flows_match_the_oracle or test_realbasicvsr_training_vs_oracle or "
+           "test_backward_is_linear_in_cotangent_large or (test_basicvsr_config1_all_grads_vs_oracle and bf16)")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -112,7 +112,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     loaded = _lib.load()                                 # sets argtypes for every export
-    assert loaded.vsr_abi_version() == 2
+    assert loaded.vsr_abi_version() == 3
     assert loaded.vsr_status_string(-4) == b"workspace too small"
 
 
@@ -124,6 +124,13 @@ def test_workspace_query_and_unsupported_configs_fail_loudly():
     train = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(d), 1)
     infer = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(d), 0)
     assert 100e9 < train < 200e9 and 3e9 < infer < 12e9   # sized for 288 GB of HBM3E
+    # arena_mode 1 ("diet", ABI 3): <= 70 GiB for BASELINE config 2, i.e. two clips per GPU (round-2 VERDICT #8); inference ignores it
+    diet = _lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 4, _lib.DT_BF16, 1)
+    for mode in (1, 2):
+        full_b, diet_b = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(d), mode), lib.vsr_basicvsr_workspace_bytes(ctypes.byref(diet), mode)
+        assert 0 < diet_b <= 70 * 2 ** 30 and diet_b < 0.55 * full_b, (mode, diet_b / 2 ** 30, full_b / 2 ** 30)
+    assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(diet), 0) == infer
+    assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(_lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 4, 1, 2)), 1) == 0
     for bad in (_lib.BasicVSRDesc(1, 7, 540, 960, 32, 30, 4, 1), _lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 2, 1),
                 _lib.BasicVSRDesc(1, 7, 540, 960, 64, 0, 4, 1)):
         assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(bad), 1) == 0

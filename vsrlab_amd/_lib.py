@@ -17,7 +17,7 @@ DT_BF16 = 1
 class BasicVSRDesc(ctypes.Structure):
     """struct VsrBasicVSRDesc (include/vsrlab_hip.h)."""
     _fields_ = [("n", c_int), ("t", c_int), ("h", c_int), ("w", c_int), ("mid_channels", c_int),
-                ("res_blocks", c_int), ("upscale", c_int), ("dtype", c_int)]
+                ("res_blocks", c_int), ("upscale", c_int), ("dtype", c_int), ("arena_mode", c_int)]
 
 
 class DiscDesc(ctypes.Structure):

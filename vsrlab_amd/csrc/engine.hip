@@ -86,6 +86,7 @@ struct SpyPlan {
 struct Plan {
     VsrBasicVSRDesc d;
     bool bwd, flowgrad;          // flowgrad: train_flow (basicvsr.py:25-28), SPyNet is differentiated too
+    bool diet;                   // VsrBasicVSRDesc.arena_mode = 1 (training only): see vsrlab_hip.h
     int rb, n, t, h, w, dtype;
     size_t es;
     size_t px1;                 // elements of one blocked (n,h,w,64) tensor
@@ -121,11 +122,15 @@ struct Plan {
     size_t xoff(int dir, int i, int b) const { return X[dir][(size_t)i * (rb + 1) + b]; }
     size_t aoff(int dir, int i, int b) const { return A[dir][(size_t)i * rb + b]; }
     size_t sboff(int dir, int i, int b) const { return SB[dir][(size_t)i * rb + b]; }
-    size_t g1off(int dir, int i, int b) const { return G1[dir][(size_t)i * rb + b]; }
-    size_t dxoff(int dir, int i, int b) const { return DX[dir][(size_t)i * (rb + 1) + b]; }
+    // diet: the trunk's activation gradients live in a ring of two buffers per kind and direction (block parity): a block's weight
+    // gradients are launched right behind its data gradients, on the same stream, so its buffers are free two blocks later
+    size_t g1off(int dir, int i, int b) const { return diet ? G1[dir][b & 1] : G1[dir][(size_t)i * rb + b]; }
+    size_t dxoff(int dir, int i, int b) const { return diet ? DX[dir][b & 1] : DX[dir][(size_t)i * (rb + 1) + b]; }
 
     int build(const VsrBasicVSRDesc& desc, int mode) {     // 0 inference, 1 training (frozen flow), 2 training incl. SPyNet
         d = desc; bwd = mode >= 1; flowgrad = mode >= 2;
+        if (d.arena_mode != 0 && d.arena_mode != 1) return VSR_ERR_BADARG;
+        diet = bwd && d.arena_mode == 1;
         rb = d.res_blocks; n = d.n; t = d.t; h = d.h; w = d.w; dtype = d.dtype;
         if (d.mid_channels != C || d.upscale != 4 || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
         if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
@@ -170,7 +175,12 @@ struct Plan {
         for (int dir = 0; dir < 2; ++dir) { scratchA[dir] = b.take(a1); scratchW[dir] = b.take(a1); }
         const int nrec = bwd ? t : 1;
         Pt.assign(t, 0); U0.assign(t, 0); U1.assign(t, 0); C0.assign(t, 0);
-        for (int i = 0; i < nrec; ++i) { Pt[i] = b.take(a1); U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
+        // diet: the upsampled tensors of a frame (U0, U1 = the upsample layers' outputs, C0 = conv_last.0's) are not kept: one shared
+        // buffer each, recomputed from Pt[i] at the top of the frame's reconstruction backward (2.4 GB per frame at 540p x4)
+        for (int i = 0; i < nrec; ++i) {
+            Pt[i] = b.take(a1);
+            if (diet && i > 0) { U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; } else { U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
+        }
         for (int i = nrec; i < t; ++i) { Pt[i] = Pt[0]; U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; }
         SBC0.assign(t, 0); SBPt.assign(t, 0);
         if (bwd && dtype == VSR_BF16)
@@ -180,18 +190,26 @@ struct Plan {
             }
         if (bwd) {
             for (int dir = 0; dir < 2; ++dir) {
-                G0[dir].assign(t, 0); G1[dir].assign((size_t)t * rb, 0); DX[dir].assign((size_t)t * (rb + 1), 0);
-                for (int i = 0; i < t; ++i) {
-                    G0[dir][i] = b.take(a1);
-                    for (int k = 0; k < rb; ++k) G1[dir][(size_t)i * rb + k] = b.take(a1);
-                    for (int k = 1; k <= rb; ++k) DX[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
+                G0[dir].assign(t, 0);
+                for (int i = 0; i < t; ++i) G0[dir][i] = b.take(a1);
+                if (diet) {
+                    G1[dir].assign(2, 0); DX[dir].assign(2, 0);
+                    for (int k = 0; k < 2; ++k) { G1[dir][k] = b.take(a1); DX[dir][k] = b.take(a1); }
+                } else {
+                    G1[dir].assign((size_t)t * rb, 0); DX[dir].assign((size_t)t * (rb + 1), 0);
+                    for (int i = 0; i < t; ++i) {
+                        for (int k = 0; k < rb; ++k) G1[dir][(size_t)i * rb + k] = b.take(a1);
+                        for (int k = 1; k <= rb; ++k) DX[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
+                    }
                 }
             }
             dFeatB.assign(t, 0); dFF.assign(t, 0);
             for (int i = 0; i < t; ++i) { dFeatB[i] = b.take(a1); dFF[i] = b.take(a1); }
             for (int dir = 0; dir < 2; ++dir) { S[dir] = b.take(s_elems * 8); dWp[dir] = b.take(a1); }
             far_cnt = b.take((size_t)2 * 32 * 4);
-            G_C0 = b.take(a4); G_U1 = b.take(a4); G_U0 = b.take(a2); G_P = b.take(a1);
+            G_C0 = b.take(a4); G_P = b.take(a1);
+            // diet: dU1 is written after C0's last use and dU0 after U1's (recon_backward): they take those buffers
+            if (diet) { G_U1 = C0[0]; G_U0 = U1[0]; } else { G_U1 = b.take(a4); G_U0 = b.take(a2); }
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
@@ -658,6 +676,11 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
 int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g, const float* last2_w) {
     const PIdx ix{p.rb};
     const WG wg{c};
+    if (p.diet) {   // U0, U1 and C0 of this frame were not kept: the forward's three launches again (the sign bits of C0 were)
+        CK(c.conv_ps(c.at(p.Pt[i]), p.up_w[0], c.fat(p.up_b[0]), c.at(p.U0[i]), p.n, p.h, p.w));
+        CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), p.n, 2 * p.h, 2 * p.w));
+        CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, p.n, 4 * p.h, 4 * p.w, nullptr));
+    }
     const int n = p.n, h = p.h, w = p.w, H4 = 4 * h, W4 = 4 * w;
     const float* dsr_i = dsr + (size_t)i * 3 * H4 * W4;
     const long long dsr_ns = (long long)p.t * 3 * H4 * W4;
@@ -713,7 +736,12 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
 // BPTT through one ResidualBlock call; top gradient = dtop (T) + S (fp32 scatter, optional)
 // pending_flow: the flow of the warp whose output gradient sits in dWp[dir] (from the previous frame of the chain), or null:
 // the top gradient of this frame is dtop + warp^T(dWp) -- gather form, fused with the cast (elementwise.hip)
-int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, const float* pending_flow, int pending_k, bool has_warp) {
+int stem_wgrads(const Ctx& c, const Plan& p, int dir, int f0, int f1, const float* lrs, float* const* g);
+int block_wgrads(const Ctx& c, const Plan& p, int dir, int b, int f0, int f1, float* const* g);
+// diet (Plan::diet): the frame's weight gradients are launched here, block by block behind the data gradients (one frame per
+// launch, accumulated into g), because the activation gradients are not kept for backward_chain's all-frames launches
+int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop, const float* pending_flow, int pending_k, bool has_warp,
+                   const float* lrs, float* const* g) {
     const int n = p.n, h = p.h, w = p.w, rb = p.rb;
     if (pending_flow) {
         const long long fstride = (long long)(p.t - 1) * 2 * h * w;
@@ -731,44 +759,56 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
         void* out = b > 0 ? c.at(p.dxoff(dir, i, b)) : c.at(p.G0[dir][i]);
         CK(c.conv64(c.at(p.g1off(dir, i, b)), p.blk_wd[dir][2 * b], nullptr, out, ACT_NONE, dxn, b == 0 ? c.at(p.xoff(dir, i, 0)) : nullptr,
                     b == 0 ? MASK_LEAKY : 0, n, h, w, nullptr, (b == 0 && c.dtype == VSR_BF16) ? c.at(p.SBX0[dir][i]) : nullptr));
+        if (p.diet) CK(block_wgrads(c, p, dir, b, i, i + 1, g));
     }
     if (has_warp)   // gradient w.r.t. the warped state (feat part of the stem's input)
         CK(c.conv64(c.at(p.G0[dir][i]), p.stem_wd[dir], nullptr, c.at(p.dWp[dir]), ACT_NONE, nullptr, nullptr, 0, n, h, w));
+    if (p.diet) CK(stem_wgrads(c, p, dir, i, i + 1, lrs, g));
     return VSR_OK;
 }
 
-int trunk_wgrads(const Ctx& c, const Plan& p, int dir, const float* lrs, float* const* g) {
+// Weight gradients of one direction's trunk for the frames [f0, f1) (at most VSR_WG_MAXSEG per launch): the stem ...
+int stem_wgrads(const Ctx& c, const Plan& p, int dir, int f0, int f1, const float* lrs, float* const* g) {
     const PIdx ix{p.rb};
     const WG wg{c};
-    const int n = p.n, t = p.t, h = p.h, w = p.w, rb = p.rb;
-    for (int i0 = 0; i0 < t; i0 += VSR_WG_MAXSEG) {
-        const int i1 = i0 + VSR_WG_MAXSEG < t ? i0 + VSR_WG_MAXSEG : t;
-        {   // stem, LR part (+ bias)
-            WgradArgs a = wg_base(n, h, w);
-            a.nseg = 0;
-            for (int i = i0; i < i1; ++i) { a.x[a.nseg] = lrs + (size_t)i * 3 * h * w; a.dy[a.nseg] = c.at(p.G0[dir][i]); ++a.nseg; }
-            a.x_nstride = (long long)t * 3 * h * w;
-            CK(wg.run(3, 16, true, 64, false, a, C, 3, g[ix.stem_w(dir)], C + 3, 0, 1, 0, g[ix.stem_b(dir)]));
+    const int n = p.n, t = p.t, h = p.h, w = p.w;
+    {   // LR part (+ bias)
+        WgradArgs a = wg_base(n, h, w);
+        a.nseg = 0;
+        for (int i = f0; i < f1; ++i) { a.x[a.nseg] = lrs + (size_t)i * 3 * h * w; a.dy[a.nseg] = c.at(p.G0[dir][i]); ++a.nseg; }
+        a.x_nstride = (long long)t * 3 * h * w;
+        CK(wg.run(3, 16, true, 64, false, a, C, 3, g[ix.stem_w(dir)], C + 3, 0, 1, 0, g[ix.stem_b(dir)]));
+    }
+    {   // feat part: only frames that had a warped state
+        WgradArgs a = wg_base(n, h, w);
+        a.nseg = 0;
+        for (int i = f0; i < f1; ++i) {
+            const bool has = dir == 0 ? (i < t - 1) : (i > 0);
+            if (has) { a.x[a.nseg] = c.at(p.Wp[dir][i]); a.dy[a.nseg] = c.at(p.G0[dir][i]); ++a.nseg; }
         }
-        {   // stem, feat part: only frames that had a warped state
-            WgradArgs a = wg_base(n, h, w);
-            a.nseg = 0;
-            for (int i = i0; i < i1; ++i) {
-                const bool has = dir == 0 ? (i < t - 1) : (i > 0);
-                if (has) { a.x[a.nseg] = c.at(p.Wp[dir][i]); a.dy[a.nseg] = c.at(p.G0[dir][i]); ++a.nseg; }
-            }
-            if (a.nseg) CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.stem_w(dir)], C + 3, 3, 1, 0, nullptr));
-        }
-        for (int b = 0; b < rb; ++b) {
-            WgradArgs a1 = wg_base(n, h, w), a2 = wg_base(n, h, w);
-            a1.nseg = a2.nseg = 0;
-            for (int i = i0; i < i1; ++i) {
-                a1.x[a1.nseg] = c.at(p.xoff(dir, i, b)); a1.dy[a1.nseg] = c.at(p.g1off(dir, i, b)); ++a1.nseg;
-                a2.x[a2.nseg] = c.at(p.aoff(dir, i, b)); a2.dy[a2.nseg] = c.at(p.dxoff(dir, i, b + 1)); ++a2.nseg;
-            }
-            CK(wg.run(3, 64, false, 64, false, a1, C, C, g[ix.blk_w(dir, 2 * b)], C, 0, 1, 0, g[ix.blk_b(dir, 2 * b)]));
-            CK(wg.run(3, 64, false, 64, false, a2, C, C, g[ix.blk_w(dir, 2 * b + 1)], C, 0, 1, 0, g[ix.blk_b(dir, 2 * b + 1)]));
-        }
+        if (a.nseg) CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.stem_w(dir)], C + 3, 3, 1, 0, nullptr));
+    }
+    return VSR_OK;
+}
+// ... and the two convs of ResidualConv block b
+int block_wgrads(const Ctx& c, const Plan& p, int dir, int b, int f0, int f1, float* const* g) {
+    const PIdx ix{p.rb};
+    const WG wg{c};
+    WgradArgs a1 = wg_base(p.n, p.h, p.w), a2 = wg_base(p.n, p.h, p.w);
+    a1.nseg = a2.nseg = 0;
+    for (int i = f0; i < f1; ++i) {
+        a1.x[a1.nseg] = c.at(p.xoff(dir, i, b)); a1.dy[a1.nseg] = c.at(p.g1off(dir, i, b)); ++a1.nseg;
+        a2.x[a2.nseg] = c.at(p.aoff(dir, i, b)); a2.dy[a2.nseg] = c.at(p.dxoff(dir, i, b + 1)); ++a2.nseg;
+    }
+    CK(wg.run(3, 64, false, 64, false, a1, C, C, g[ix.blk_w(dir, 2 * b)], C, 0, 1, 0, g[ix.blk_b(dir, 2 * b)]));
+    CK(wg.run(3, 64, false, 64, false, a2, C, C, g[ix.blk_w(dir, 2 * b + 1)], C, 0, 1, 0, g[ix.blk_b(dir, 2 * b + 1)]));
+    return VSR_OK;
+}
+int trunk_wgrads(const Ctx& c, const Plan& p, int dir, const float* lrs, float* const* g) {
+    for (int i0 = 0; i0 < p.t; i0 += VSR_WG_MAXSEG) {
+        const int i1 = i0 + VSR_WG_MAXSEG < p.t ? i0 + VSR_WG_MAXSEG : p.t;
+        CK(stem_wgrads(c, p, dir, i0, i1, lrs, g));
+        for (int b = 0; b < p.rb; ++b) CK(block_wgrads(c, p, dir, b, i0, i1, g));
     }
     return VSR_OK;
 }
@@ -786,7 +826,7 @@ int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float
         const int i = dir == 1 ? t - 1 - k : k;
         const void* dtop = dir == 1 ? c.at(p.dFF[i]) : c.at(p.dFeatB[i]);
         const bool last = k == t - 1;                     // the chain's first frame had no warped state
-        CK(trunk_backward(c, p, dir, i, dtop, pending, k, !last));
+        CK(trunk_backward(c, p, dir, i, dtop, pending, k, !last, lrs, g));
         pending = nullptr;
         if (!last) {   // feat(i) = trunk(warp(feat(prev), flow)): the gradient of the warped state goes back through the warp
             pending = flow_ptr(c, p, dir, dir == 1 ? i - 1 : i);     // ... at the top of the next frame's trunk_backward
@@ -797,7 +837,7 @@ int backward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs, float
             }
         }
     }
-    return trunk_wgrads(c, p, dir, lrs, g);
+    return p.diet ? VSR_OK : trunk_wgrads(c, p, dir, lrs, g);
 }
 
 int backward_impl(const Plan& p, const float* const* prm, float* const* g, const float* lrs, const float* dsr, float* dlrs,
@@ -832,7 +872,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
 // ================================ C ABI =========================================================
 extern "C" {
 
-int vsr_abi_version(void) { return 2; }
+int vsr_abi_version(void) { return 3; }
 
 const char* vsr_status_string(int s) {
     switch (s) {

@@ -344,8 +344,8 @@ class _CtxToken:
 class _BasicVSRFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lrs, desc_tuple, pool, n_trainable, need_bwd, direct, *params):
-        n, t, h, w, mid, rb, up, dtype = desc_tuple
-        desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
+        n, t, h, w, mid, rb, up, dtype, arena = desc_tuple
+        desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype, arena)
         lib = _lib.load()
         nbytes = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(desc), int(need_bwd))
         if nbytes == 0:
@@ -380,8 +380,8 @@ class _BasicVSRFn(torch.autograd.Function):
             # overwritten the saved activations): fail like PyTorch does for freed buffers instead of returning garbage
             raise RuntimeError("vsrlab_amd: trying to backward through the BasicVSR graph a second time: the saved "
                                "activations live in a pooled workspace that was released by the first backward")
-        n, t, h, w, mid, rb, up, dtype = ctx.desc_tuple
-        desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype)
+        n, t, h, w, mid, rb, up, dtype, arena = ctx.desc_tuple
+        desc = BasicVSRDesc(n, t, h, w, mid, rb, up, dtype, arena)
         lib = _lib.load()
         ps = ctx.ps
         # need_bwd == 2 (train_flow / input gradient): the SPyNet conv weights / biases (everything but the trailing mean,
@@ -433,6 +433,29 @@ class _BasicVSRFn(torch.autograd.Function):
         return (dlrs, None, None, None, None, None) + tuple(grads)
 
 
+_ARENA_MODE: Optional[int] = None
+
+
+def set_arena_mode(mode: Optional[str]) -> None:
+    """Training workspace of the BasicVSR engine (VsrBasicVSRDesc.arena_mode, include/vsrlab_hip.h): "full" (default: every
+    activation gradient kept, all-frames weight-gradient launches; 127 GiB for BASELINE config 2) or "diet" (63 GiB: per-frame
+    weight gradients behind a two-block gradient ring, HR activations recomputed; for batch-of-clips per GPU).  None: back to
+    $VSRLAB_AMD_ARENA (unset = "full")."""
+    global _ARENA_MODE
+    if mode is not None and mode not in ("full", "diet"):
+        raise ValueError("arena mode is 'full' or 'diet'")
+    _ARENA_MODE = None if mode is None else int(mode == "diet")
+
+
+def arena_mode() -> int:
+    if _ARENA_MODE is not None:
+        return _ARENA_MODE
+    env = os.environ.get("VSRLAB_AMD_ARENA", "full")
+    if env not in ("full", "diet"):
+        raise ValueError("VSRLAB_AMD_ARENA is 'full' or 'diet'")
+    return int(env == "diet")
+
+
 def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_trainable: int, mid_channels: int,
                      res_blocks: int, upscale: int, pool: WorkspacePool, compute_dtype: Optional[str] = None) -> torch.Tensor:
     """sr = BasicVSR(lrs) on the HIP engine.  ``params`` in state_dict order; the first
@@ -443,7 +466,7 @@ def basicvsr_forward(lrs: torch.Tensor, params: Sequence[torch.Tensor], n_traina
     if lrs.dim() != 5 or lrs.shape[2] != 3:
         raise ValueError("lrs must be (n,t,3,h,w)")
     n, t, _, h, w = lrs.shape
-    desc_tuple = (n, t, h, w, mid_channels, res_blocks, upscale, resolve_dtype(compute_dtype))
+    desc_tuple = (n, t, h, w, mid_channels, res_blocks, upscale, resolve_dtype(compute_dtype), arena_mode())
     # grad mode is off inside Function.forward, so decide here whether activations must be retained
     need_bwd = 0
     if torch.is_grad_enabled():
