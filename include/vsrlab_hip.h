@@ -114,16 +114,19 @@ int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int
 
 /* Forward of the canonical SPyNet variants: last_relu = 0 drops the ReLU the RealBasicVSR copy has after every level's last
  * conv (vsr/models/VRT/modules/spynet.py:68-157); level_out: HOST array of 6 device pointers (NULL = not wanted), entry l
- * receives level l's flow resized to (N,2, h >> (5-l), w >> (5-l)) -- VRT's return_levels.  Same workspace query.      */
+ * receives level l's flow resized to (N,2, h >> (5-l), w >> (5-l)) -- VRT's return_levels.  Same workspace query;
+ * need_backward != 0 (ABI 3) keeps the activations for vsr_spynet_backward_ex.                                          */
 int vsr_spynet_forward_ex(int N, int h, int w, int dtype, const float* const* params, int nparams, const float* ref,
                           const float* supp, int last_relu, float* const* level_out, void* workspace,
-                          size_t workspace_bytes, void* stream);
-/* The same plus the gradient w.r.t. the two input frames (through the border warps, the image pyramid, the /32 resize and
- * the normalisation): dref, dsupp (N,3,h,w) fp32 are WRITTEN (either may be NULL); grads may be NULL (frozen flow net);
- * params: the forward's 62 tensors.                                                                                 */
+                          size_t workspace_bytes, int need_backward, void* stream);
+/* Backward of vsr_spynet_forward / _forward_ex (need_backward != 0) incl. the gradient w.r.t. the two input frames (through
+ * the border warps, the image pyramid, the /32 resize and the normalisation): dref, dsupp (N,3,h,w) fp32 are WRITTEN
+ * (either may be NULL); grads may be NULL (frozen flow net); params: the forward's 62 tensors.  Cotangents: dflow (N,2,h,w)
+ * of the full-resolution flow and / or (ABI 3) dlevel, a HOST array of 6 device pointers (NULL = none) in the layout of
+ * forward_ex's level_out; last_relu as in the forward (vsr_spynet_forward: 1).                                          */
 int vsr_spynet_backward_ex(int N, int h, int w, int dtype, const float* const* params, float* const* grads, int nparams,
-                           const float* dflow, float* dref, float* dsupp, void* workspace, size_t workspace_bytes,
-                           void* stream);
+                           const float* dflow, int last_relu, const float* const* dlevel, float* dref, float* dsupp,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- RealBasicVSR pre-clean stack, forward: lq = IterativeRefinement(lr) ----------------------
  * (vsr/models/RealBasicVSR/realbasicvsr.py:17-30): `steps` times x <- x + conv(ResidualBlock(x)) on

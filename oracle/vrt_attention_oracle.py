@@ -137,7 +137,7 @@ def vrt_spynet_forward(sd: Mapping[str, Tensor], ref: Tensor, supp: Tensor, retu
     """SpyNet.forward / .process of the VRT tree (vsr/models/VRT/modules/spynet.py:98-157): the canonical SPyNet -- no ReLU
     after a level's last conv (:68-82), keys basic_module.{l}.basic_module.{0,2,4,6,8} -- returning the flows of the
     requested pyramid levels, finest first, each resized to (h // scale, w // scale) and rescaled (:134-141)."""
-    from .basicvsr_oracle import flow_warp
+    from .basicvsr_oracle import flow_warp, _q, _wq      # _q / _wq: identity unless the oracle emulates bf16 storage (emulate_bf16)
     import math
     h, w = ref.shape[2:]
     w_floor = math.floor(math.ceil(w / 32.0) * 32.0)
@@ -156,12 +156,12 @@ def vrt_spynet_forward(sd: Mapping[str, Tensor], ref: Tensor, supp: Tensor, retu
             up = F.pad(up, [0, 0, 0, 1], mode="replicate")
         if up.size(3) != refs[level].size(3):
             up = F.pad(up, [0, 1, 0, 0], mode="replicate")
-        x = torch.cat([refs[level], flow_warp(supps[level], up, padding_mode="border"), up], 1)
+        x = _q(torch.cat([refs[level], flow_warp(supps[level], up, padding_mode="border"), up], 1))
         for j in (0, 2, 4, 6, 8):
             k = f"basic_module.{level}.basic_module.{j}."
-            x = F.conv2d(x, sd[k + "weight"], sd[k + "bias"], padding=3)
+            x = F.conv2d(x, _wq(sd[k + "weight"]), sd[k + "bias"], padding=3)
             if j < 8:
-                x = F.relu(x)
+                x = _q(F.relu(x))
         flow = x + up
         if level in return_levels:
             scale = 2 ** (5 - level)

@@ -43,8 +43,8 @@ _SIGNATURES = {
     "vsr_spynet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "vsr_spynet_forward": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "vsr_spynet_backward": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
-    "vsr_spynet_forward_ex": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_size_t, _P]),
-    "vsr_spynet_backward_ex": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "vsr_spynet_forward_ex": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_size_t, c_int, _P]),
+    "vsr_spynet_backward_ex": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "vsr_cleaner_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vsr_cleaner_forward": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_size_t, c_int, _P]),
     "vsr_cleaner_backward": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),

@@ -547,8 +547,8 @@ __global__ void spynet_dres_kernel(const float* __restrict__ dflow, const float*
         const long long p = idx / hw;
         const long long o = (p * 2) * hw + (long long)y * w + x;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        v[0] = res[o] > 0.f ? dflow[o] : 0.f;
-        v[1] = res[o + hw] > 0.f ? dflow[o + hw] : 0.f;
+        v[0] = (!res || res[o] > 0.f) ? dflow[o] : 0.f;             // res == NULL: no ReLU behind the last conv (the canonical SPyNet of the VRT tree)
+        v[1] = (!res || res[o + hw] > 0.f) ? dflow[o + hw] : 0.f;
         typename EW<T>::chunk_t lo, hi;
         pack8(v, lo);
         pack8(z, hi);

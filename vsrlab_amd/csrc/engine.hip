@@ -611,20 +611,25 @@ WgradArgs wg_base(int N, int H, int W) {
 // Backward of spynet_run for train_flow (spynet.py:38-93): dflows_out = d loss / d flows (P,2,h,w) ->
 // weight / bias gradients of the 6 x 5 convs (g[base_idx ...], OIHW fp32).  The frames are not differentiated.
 // dframes (optional): (F,3,h,w) fp32, ACCUMULATED into: the gradient w.r.t. the input frames (through the pyramid).
+// last_relu = false: the canonical SPyNet (no ReLU behind a level's last conv); dlevel (optional, 6 entries, NULL = none):
+// cotangents of the per-level outputs of spynet_run's level_out (VRT's return_levels); dflows_out may then be NULL.
 int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, int n, int t, int pair_mode, float* const* g,
-                    int base_idx, float* dframes = nullptr, const float* std = nullptr) {
+                    int base_idx, float* dframes = nullptr, const float* std = nullptr, bool last_relu = true,
+                    const float* const* dlevel = nullptr) {
     const WG wg{c};
     const int P = sp.P, hu = sp.hu, wu = sp.wu;
     size_t dcur = sp.dfa, dprev = sp.dfb;
     HIP_CHECK_RET(hipMemsetAsync(c.at(dcur), 0, (size_t)P * 2 * hu * wu * 4, c.st));
-    CK(vsr_launch_flow_out_bwd(dflows_out, (float*)c.at(dcur), P, hu, wu, sp.h, sp.w, c.st));
+    if (dflows_out) CK(vsr_launch_flow_out_bwd(dflows_out, (float*)c.at(dcur), P, hu, wu, sp.h, sp.w, c.st));
     if (dframes)
         for (int l = 0; l < 6; ++l)
             HIP_CHECK_RET(hipMemsetAsync(c.at(sp.dpyr[l]), 0, (size_t)sp.F * 3 * (hu >> (5 - l)) * (wu >> (5 - l)) * 4, c.st));
     for (int l = 5; l >= 0; --l) {
         const int hl = hu >> (5 - l), wl = wu >> (5 - l);
+        if (dlevel && dlevel[l])   // this level's flow was also an output (resized to the frame's own pyramid size): add its cotangent
+            CK(vsr_launch_flow_out_bwd(dlevel[l], (float*)c.at(dcur), P, hl, wl, sp.h >> (5 - l), sp.w >> (5 - l), c.st));
         // flow_l = flow_up + ReLU(conv5): dY of the last conv, as a 16-channel pixel-major tensor
-        CK(vsr_launch_spynet_dres(c.dtype, c.fat(dcur), c.fat(sp.sres[l]), c.at(sp.dres), P, hl, wl, c.st));
+        CK(vsr_launch_spynet_dres(c.dtype, c.fat(dcur), last_relu ? c.fat(sp.sres[l]) : nullptr, c.at(sp.dres), P, hl, wl, c.st));
         size_t dy = sp.dres;
         for (int j = NSPY - 1; j >= 0; --j) {
             const int CI = SPY_CIP[j], CO = SPY_DK[j];
@@ -978,10 +983,10 @@ int vsr_spynet_forward(int N, int h, int w, int dtype, const float* const* param
  * receives the flow of pyramid level l resized to (h >> (5-l), w >> (5-l)) (its `return_levels`).  Forward only.       */
 int vsr_spynet_forward_ex(int N, int h, int w, int dtype, const float* const* params, int nparams, const float* ref,
                           const float* supp, int last_relu, float* const* level_out, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+                          int need_backward, void* stream) {
     if (N < 1 || h < 32 || w < 32 || !params || nparams != 62 || !ref || !supp || !level_out || !workspace) return VSR_ERR_BADARG;
     if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
-    const SpyAlone s = spy_alone_plan(N, h, w, dtype, false);
+    const SpyAlone s = spy_alone_plan(N, h, w, dtype, need_backward != 0);
     if (workspace_bytes < s.total) return VSR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Plan dummy; dummy.es = esize(dtype);
@@ -1008,8 +1013,12 @@ int vsr_spynet_backward(int N, int h, int w, int dtype, float* const* grads, int
 /* the same, plus the gradient w.r.t. the two input frames: dref, dsupp (N,3,h,w) fp32 are WRITTEN (either may be NULL).
  * params: the 62 tensors of the forward (std is needed for the normalisation's adjoint); grads may be NULL (frozen net). */
 int vsr_spynet_backward_ex(int N, int h, int w, int dtype, const float* const* params, float* const* grads, int nparams, const float* dflow,
-                           float* dref, float* dsupp, void* workspace, size_t workspace_bytes, void* stream) {
-    if (N < 1 || h < 1 || w < 1 || !params || nparams != 62 || !dflow || !workspace || !params[61]) return VSR_ERR_BADARG;
+                           int last_relu, const float* const* dlevel, float* dref, float* dsupp, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    if (N < 1 || h < 1 || w < 1 || !params || nparams != 62 || !workspace || !params[61]) return VSR_ERR_BADARG;
+    bool any = dflow != nullptr;
+    if (dlevel) for (int l = 0; l < 6; ++l) any = any || dlevel[l];
+    if (!any) return VSR_ERR_BADARG;
     if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
     if (grads) for (int k = 0; k < 60; k += 2) if (!grads[k] && grads[k + 1]) return VSR_ERR_BADARG;
     const SpyAlone s = spy_alone_plan(N, h, w, dtype, true);
@@ -1020,7 +1029,7 @@ int vsr_spynet_backward_ex(int N, int h, int w, int dtype, const float* const* p
     const bool want = dref || dsupp;
     const size_t fb = (size_t)N * 3 * h * w * 4;
     if (want) HIP_CHECK_RET(hipMemsetAsync(c.at(s.dframes), 0, 2 * fb, st));
-    CK(spynet_backward(c, s.sp, dflow, N, 2, 1, grads, 0, want ? (float*)c.at(s.dframes) : nullptr, params[61]));
+    CK(spynet_backward(c, s.sp, dflow, N, 2, 1, grads, 0, want ? (float*)c.at(s.dframes) : nullptr, params[61], last_relu != 0, dlevel));
     if (dref) HIP_CHECK_RET(hipMemcpyAsync(dref, c.at(s.dframes), fb, hipMemcpyDeviceToDevice, st));
     if (dsupp) HIP_CHECK_RET(hipMemcpyAsync(dsupp, (char*)c.at(s.dframes) + fb, fb, hipMemcpyDeviceToDevice, st));
     return VSR_OK;

@@ -252,7 +252,7 @@ class _SpynetFn(torch.autograd.Function):
         dref = torch.empty((n, 3, h, w), dtype=torch.float32, device=dflow.device) if ctx.needs_input_grad[0] else None
         dsupp = torch.empty((n, 3, h, w), dtype=torch.float32, device=dflow.device) if ctx.needs_input_grad[1] else None
         _lib.check(lib.vsr_spynet_backward_ex(n, h, w, dtype, _ptr_array(ctx.ps), _ptr_array(grads) if want_p else None, len(grads),
-                                              _ptr(_f32c(dflow)), _ptr(dref), _ptr(dsupp), _ptr(ctx.ws), ctx.ws.numel(), _stream()),
+                                              _ptr(_f32c(dflow)), 1, None, _ptr(dref), _ptr(dsupp), _ptr(ctx.ws), ctx.ws.numel(), _stream()),
                    "spynet_backward")
         ctx.ws = None
         return (dref, dsupp, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + k]) else None
@@ -270,27 +270,71 @@ def spynet_flow(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.T
     return _SpynetFn.apply(ref, supp, resolve_dtype(compute_dtype), need_bwd, *params)
 
 
+class _SpynetLevelsFn(torch.autograd.Function):
+    """The per-level flows of the canonical SPyNet with their backward on the HIP engine (vsr_spynet_forward_ex /
+    vsr_spynet_backward_ex): parameter gradients and the gradient w.r.t. both frames, from the cotangents of every returned
+    level (vsr/models/VRT/modules/spynet.py:98-157 under autograd)."""
+
+    @staticmethod
+    def forward(ctx, ref, supp, dtype, need_bwd, last_relu, levels, *params):
+        n, _, h, w = ref.shape
+        lib = _lib.load()
+        ps = [_f32c(p) for p in params]
+        ws = torch.empty(lib.vsr_spynet_workspace_bytes(n, h, w, dtype, int(need_bwd)), dtype=torch.uint8, device=ref.device)
+        outs: List[Optional[torch.Tensor]] = [None] * 6
+        for lv in levels:
+            outs[lv] = torch.empty((n, 2, h >> (5 - lv), w >> (5 - lv)), dtype=torch.float32, device=ref.device)
+        _lib.check(lib.vsr_spynet_forward_ex(n, h, w, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(ref)), _ptr(_f32c(supp)), int(last_relu),
+                                             _ptr_array(outs), _ptr(ws), ws.numel(), int(need_bwd), _stream()), "spynet_forward_ex")
+        ctx.meta = (n, h, w, dtype, need_bwd, last_relu, levels)
+        ctx.ws = ws if need_bwd else None
+        ctx.ps = ps
+        return tuple(outs[lv] for lv in levels)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n, h, w, dtype, need_bwd, last_relu, levels = ctx.meta
+        if not need_bwd:
+            raise RuntimeError("vsrlab_amd: backward through a SPyNet forward that ran without need_backward")
+        if ctx.ws is None:
+            raise RuntimeError("vsrlab_amd: trying to backward through the SPyNet graph a second time")
+        lib = _lib.load()
+        dlevel: List[Optional[torch.Tensor]] = [None] * 6
+        for lv, d in zip(levels, douts):
+            if d is not None:
+                dlevel[lv] = _f32c(d)
+        want_p = any(ctx.needs_input_grad[6 + k] for k in range(60))
+        grads = [torch.zeros_like(p) if (k < 60 and want_p) else None for k, p in enumerate(ctx.ps)]
+        dev = ctx.ps[0].device
+        dref = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dsupp = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        if all(d is None for d in dlevel):
+            if dref is not None:
+                dref.zero_()
+            if dsupp is not None:
+                dsupp.zero_()
+        else:
+            _lib.check(lib.vsr_spynet_backward_ex(n, h, w, dtype, _ptr_array(ctx.ps), _ptr_array(grads) if want_p else None, len(grads),
+                                                  None, int(last_relu), _ptr_array(dlevel), _ptr(dref), _ptr(dsupp), _ptr(ctx.ws),
+                                                  ctx.ws.numel(), _stream()), "spynet_backward")
+        ctx.ws = None
+        return (dref, dsupp, None, None, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[6 + k]) else None
+                                                             for k, g in enumerate(grads))
+
+
 def spynet_levels(params: Sequence[torch.Tensor], ref: torch.Tensor, supp: torch.Tensor, return_levels: Sequence[int],
                   last_relu: bool = False, compute_dtype: Optional[str] = None) -> List[torch.Tensor]:
-    """Forward of the canonical SPyNet (vsr/models/VRT/modules/spynet.py:68-157): the flows of the requested pyramid
-    levels (5 = full resolution, 4 = 1/2, ...), finest first, like the reference's ``flow_list``.  Inference only."""
+    """The canonical SPyNet (vsr/models/VRT/modules/spynet.py:68-157): the flows of the requested pyramid levels (5 = full
+    resolution, 4 = 1/2, ...), finest first, like the reference's ``flow_list``; differentiable w.r.t. the 60 conv tensors
+    and both frames."""
     _require_gpu(ref, supp)
-    if torch.is_grad_enabled() and (ref.requires_grad or supp.requires_grad or any(p.requires_grad for p in params[:60])):
-        raise NotImplementedError("the multi-level SPyNet forward is inference-only on the HIP path: call it under torch.no_grad() "
-                                  "or freeze it (the BasicVSR path's Spynet is the differentiable one)")
-    n, _, h, w = ref.shape
-    lib = _lib.load()
-    dtype = resolve_dtype(compute_dtype)
-    ps = [_f32c(p) for p in params]
-    ws = torch.empty(lib.vsr_spynet_workspace_bytes(n, h, w, dtype, 0), dtype=torch.uint8, device=ref.device)
-    outs: List[Optional[torch.Tensor]] = [None] * 6
-    for lv in set(int(v) for v in return_levels):
-        if not 0 <= lv <= 5:
-            raise ValueError("return_levels are pyramid levels 0..5")
-        outs[lv] = torch.empty((n, 2, h >> (5 - lv), w >> (5 - lv)), dtype=torch.float32, device=ref.device)
-    _lib.check(lib.vsr_spynet_forward_ex(n, h, w, dtype, _ptr_array(ps), len(ps), _ptr(_f32c(ref)), _ptr(_f32c(supp)), int(last_relu),
-                                         _ptr_array(outs), _ptr(ws), ws.numel(), _stream()), "spynet_forward_ex")
-    return [outs[lv] for lv in sorted(set(int(v) for v in return_levels), reverse=True)]
+    if len(params) != 62:
+        raise ValueError("expected the 62 tensors of SpyNet.state_dict()")
+    levels = tuple(sorted(set(int(v) for v in return_levels), reverse=True))
+    if not levels or not all(0 <= lv <= 5 for lv in levels):
+        raise ValueError("return_levels are pyramid levels 0..5")
+    need_bwd = torch.is_grad_enabled() and (ref.requires_grad or supp.requires_grad or any(p.requires_grad for p in params[:60]))
+    return list(_SpynetLevelsFn.apply(ref, supp, resolve_dtype(compute_dtype), need_bwd, bool(last_relu), levels, *params))
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -1,8 +1,9 @@
 """``SpyNet`` of the VRT tree (vsrlab ``src/vsr/models/VRT/modules/spynet.py:68-157``; ``_target_`` of
 ``conf/train/model/spynet.yaml``) on the HIP SPyNet engine: the canonical network (NO ReLU after a level's last conv, unlike
 the RealBasicVSR copy), ``return_levels`` multi-resolution flows, same constructor and ``state_dict`` keys
-(``basic_module.{l}.basic_module.{0,2,4,6,8}.{weight,bias}``, ``mean``, ``std``).  Inference only; frames whose size is
-not a multiple of 32 are resized like the reference does."""
+(``basic_module.{l}.basic_module.{0,2,4,6,8}.{weight,bias}``, ``mean``, ``std``).  Differentiable (parameters and both
+frames, from the cotangents of every returned level); frames whose size is not a multiple of 32 are resized like the
+reference does."""
 import logging
 import os
 
