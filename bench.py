@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--dp", default="flat", choices=["flat", "ddp"],
                     help="N > 1: flat = one all-reduce over the gradient arena (vsrlab_amd.parallel.FlatGradSync); ddp = torch DistributedDataParallel")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel leg (for rocprofv3 PMC passes)")
+    ap.add_argument("--clips", type=int, default=1, help="clips per GPU and step (BASELINE configs[3] 'batch-of-clips'; 2 fit a GPU with --arena diet)")
     ap.add_argument("--arena", default="full", choices=["full", "diet"],
                     help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 131 GiB per clip, all-frames weight-gradient launches "
                          "(the headline configuration); diet = 65 GiB per clip (per-frame weight gradients, HR activations recomputed)")
@@ -281,7 +282,7 @@ def main():
             net = DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, broadcast_buffers=False)  # core/utils.py:147-151
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
     crit = CharbonnierLoss()
-    n, t, h, w = 1, args.frames, args.height, args.width
+    n, t, h, w = args.clips, args.frames, args.height, args.width
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)             # one distinct clip per rank (weak scaling)
     lrs = torch.rand(n, t, 3, h, w, generator=g).to(dev)
     hr = torch.rand(n, t, 3, 4 * h, 4 * w, generator=g).to(dev)
@@ -328,7 +329,7 @@ def main():
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (torch.rand clips, random-init weights)",
             "config": {"workload": f"BasicVSR(mid=64,res_blocks={args.res_blocks},x4) fwd+Charbonnier+bwd+clip+Adam, "
-                                   f"{h}x{w}->{4 * h}x{4 * w}, {t}-frame clip, 1 clip per GPU (BASELINE configs[1]{'/[3]' if world > 1 else ''})",
+                                   f"{h}x{w}->{4 * h}x{4 * w}, {t}-frame clip, {n} clip{'s' if n > 1 else ''} per GPU (BASELINE configs[1]{'/[3]' if world > 1 else ''})",
                        "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "res_blocks": args.res_blocks,
                        "parallelism": (f"dp{world} (clip-level; " + ("one RCCL all-reduce of the flat gradient arena per step)" if sync is not None
                                                                         else "DDP grad all-reduce over RCCL)")) if world > 1 else "single GPU",
