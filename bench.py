@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--dp", default="flat", choices=["flat", "ddp"],
                     help="N > 1: flat = one all-reduce over the gradient arena (vsrlab_amd.parallel.FlatGradSync); ddp = torch DistributedDataParallel")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel leg (for rocprofv3 PMC passes)")
+    ap.add_argument("--train-flow", action="store_true", help="train_flow=True (conf/experiment/basic.yaml:7): SPyNet is differentiated too (need_backward = 2)")
     ap.add_argument("--clips", type=int, default=1, help="clips per GPU and step (BASELINE configs[3] 'batch-of-clips'; 2 fit a GPU with --arena diet)")
     ap.add_argument("--arena", default="full", choices=["full", "diet"],
                     help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 131 GiB per clip, all-frames weight-gradient launches "
@@ -265,7 +266,7 @@ def main():
     VF.set_arena_mode(args.arena)
 
     torch.manual_seed(0)
-    model = BasicVSR(64, args.res_blocks, 4, False, False).to(dev)
+    model = BasicVSR(64, args.res_blocks, 4, False, args.train_flow).to(dev)
     model.compute_dtype = args.dtype
     net = model
     sync = None
@@ -334,7 +335,7 @@ def main():
                        "parallelism": (f"dp{world} (clip-level; " + ("one RCCL all-reduce of the flat gradient arena per step)" if sync is not None
                                                                         else "DDP grad all-reduce over RCCL)")) if world > 1 else "single GPU",
                        "optimizer_in_timed_region": "fused clip_grad_norm(1)+Adam (HIP)" if args.optimizer == "fused" else "torch.optim.Adam",
-                       "arena": args.arena, "peak_hbm_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
+                       "arena": args.arena, "train_flow": bool(args.train_flow), "peak_hbm_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
             "loss": round(loss_val, 6), "tree": tree_id(),
         }
         bpf = algorithmic_bytes_per_frame(h, w, t, args.res_blocks, 2 if args.dtype == "bf16" else 4)

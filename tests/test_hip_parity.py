@@ -959,3 +959,32 @@ def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40), (3, 72, 200)])
+def test_spynet_7x7_weight_gradients_on_the_producer_consumer_kernel(shape):
+    """Weight / bias / input gradients of the five SPyNet layer shapes, bf16 build, through ConvReLU's autograd (vsr_conv_layer_bwd ->
+    wgrad7x7_pc.hip: all seven kernel rows in one launch, 7 x G workgroups; the data gradient stays on the generic kernel): against
+    torch autograd of the same convolution on the bf16-rounded operands (the engine also rounds the masked cotangent to bf16:
+    1e-2 relative L2), from one tile per workgroup to several (3 x 72 x 200 = 189 tiles on 32 workgroups per kernel row: both
+    buffer sets re-used), bit-identical on a repeat."""
+    dev = _gpu()
+    from vsrlab_amd import functional as VF
+    n, h, w = shape
+    for j, (ci, co) in enumerate([(8, 32), (32, 64), (64, 32), (32, 16), (16, 2)]):
+        x0 = bf16_round(rand(500 + j, n, ci, h, w, lo=-1, hi=1)).to(dev)
+        w0 = bf16_round(rand(510 + j, co, ci, 7, 7, lo=-1, hi=1) / (7.0 * ci ** 0.5)).to(dev)
+        b0 = rand(520 + j, co, lo=-0.5, hi=0.5).to(dev)
+        cot = rand(530 + j, n, co, h, w, lo=-1, hi=1).to(dev)
+
+        def run(fn):
+            x, wt, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            (fn(x, wt, b) * cot).sum().backward()
+            return x.grad, wt.grad, b.grad
+
+        got = run(lambda x, wt, b: VF.conv_relu_forward(x, wt, b, compute_dtype="bf16"))
+        want = run(lambda x, wt, b: F.relu(F.conv2d(x, wt, b, padding=3)))
+        for name, a, r in zip(("dx", "dw", "db"), got, want):
+            assert rel_l2(a, r) < 1e-2, (shape, ci, co, name, rel_l2(a, r))
+        again = run(lambda x, wt, b: VF.conv_relu_forward(x, wt, b, compute_dtype="bf16"))
+        assert all(torch.equal(a, b) for a, b in zip(got, again)), (shape, ci, co)

@@ -46,6 +46,11 @@ __device__ __forceinline__ unsigned q_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, p);
 }
 __device__ __forceinline__ unsigned q_pk_max_i16(unsigned a, unsigned b) { unsigned r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned q_pk_min_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned q_pk_mul_lo_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// ReLU' of a stored bf16 activation applied to a packed pair: both halves times (activation > 0) (bf16 patterns order like int16
+// for this purpose, see conv3x3_persist.hip)
+__device__ __forceinline__ unsigned q_relu_mask(unsigned v, unsigned act) { return q_pk_mul_lo_u16(v, q_pk_min_u16(q_pk_max_i16(act, 0u), 0x00010001u)); }
 
 #define QGLDS16(src, dst)                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
@@ -111,12 +116,12 @@ __global__ __launch_bounds__(QNT, 1) void conv7x7_persist_kernel(const ConvArgs 
     struct {
         int N, H, W, CD, act, cout_real, cop;
         long long src_nstride, dst_nstride;
-        unsigned long long src, wpack, bias, dst, pres;
+        unsigned long long src, wpack, bias, dst, pres, aux;
     } a = {ka.N, ka.H, ka.W, ka.CD, ka.act, ka.cout_real, cop, ka.src_nstride[0], ka.dst_nstride,
            (unsigned long long)ka.src[0], (unsigned long long)ka.wpack, (unsigned long long)ka.bias, (unsigned long long)ka.dst[0],
-           (unsigned long long)ka.pres};
+           (unsigned long long)ka.pres, (unsigned long long)ka.aux[0]};
     asm volatile("" : "+s"(a.N), "+s"(a.H), "+s"(a.W), "+s"(a.CD), "+s"(a.act), "+s"(a.cout_real), "+s"(a.cop), "+s"(a.src_nstride), "+s"(a.dst_nstride));
-    asm volatile("" : "+s"(a.src), "+s"(a.wpack), "+s"(a.bias), "+s"(a.dst), "+s"(a.pres));
+    asm volatile("" : "+s"(a.src), "+s"(a.wpack), "+s"(a.bias), "+s"(a.dst), "+s"(a.pres), "+s"(a.aux));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2);            // 0: MFMA + epilogue, 1: LDS-DMA producer
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(QNT, 1) void conv7x7_persist_kernel(const ConvArgs 
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) bvec[mb] = *reinterpret_cast<const f32x4_t*>(smem + K::BIAS_OFF + (mb * 16 + 4 * q) * 4);
         auto* const dstp = QGP(bf16_t, a.dst);
+        const auto* const auxp = QGP(const bf16_t, a.aux);     // MASK_RELU source (destination layout): the data gradients of train_flow
         auto* const dpl = QGP(float, a.dst);
         const auto* const ppl = QGP(const float, a.pres);
         const long long plane = (long long)a.H * a.W;
@@ -332,11 +338,30 @@ __global__ __launch_bounds__(QNT, 1) void conv7x7_persist_kernel(const ConvArgs 
                     for (int c = 0; c < 4; ++c) pr[nb][c] = (c < a.cout_real && vx < a.W && vy < a.H) ? ppl[o + c * plane] : 0.f;
                 }
             }
+            qu32x4_t mm[NB > 1 ? NB / 2 : 1][4];                // mask operand pieces of this tile, requested before the K loop
             if (hf == 0) {
 #pragma unroll
                 for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = bvec[mb];
+            }
+            if (EPI == EPI_NHWC && a.aux && (K::PASSES == 1 || hf == 1)) {
+                const long long tb = (long long)it.n * a.dst_nstride + pm_off(ty0, tx0, 0, a.W, a.CD);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const bool okn = (tx0 + (nb & 1) * 16 + pxl < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H);
+                    if constexpr (NB == 1) {
+                        qu32x2_t t2 = {0u, 0u};
+                        if (okn && (q >> 1) < CDc) t2 = *QGP(const qu32x2_t, auxp + tb + loff[nb]);
+                        mm[0][nb] = qu32x4_t{t2.x, t2.y, 0u, 0u};
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NB / 2; ++k) {
+                            mm[k][nb] = qu32x4_t{0u, 0u, 0u, 0u};
+                            if (okn && 4 * k + q < CDc) mm[k][nb] = *QGP(const qu32x4_t, auxp + tb + loff[nb] + k * 1024);
+                        }
+                    }
+                }
             }
             unsigned bb = (unsigned)(K::T_OFF + (pass % K::NTB) * K::TILE_BYTES) + b_lane;
             if constexpr (K::STREAM) {
@@ -369,6 +394,7 @@ __global__ __launch_bounds__(QNT, 1) void conv7x7_persist_kernel(const ConvArgs 
                             if constexpr (NB == 1) {                                                                   \
                                 unsigned o0 = q_pk_bf16(acc[0][nb][0], acc[0][nb][1]), o1 = q_pk_bf16(acc[0][nb][2], acc[0][nb][3]); \
                                 if (relu) { o0 = q_pk_max_i16(o0, 0u); o1 = q_pk_max_i16(o1, 0u); }                    \
+                                if (a.aux) { o0 = q_relu_mask(o0, mm[0][nb].x); o1 = q_relu_mask(o1, mm[0][nb].y); }    \
                                 if ((q >> 1) < CDc) *QGP(qu32x2_t, d) = qu32x2_t{o0, o1};                              \
                             } else {                                                                                   \
                                 _Pragma("unroll") for (int k = 0; k < NB / 2; ++k) {                                   \
@@ -378,6 +404,8 @@ __global__ __launch_bounds__(QNT, 1) void conv7x7_persist_kernel(const ConvArgs 
                                         ow[2 + jj] = q_pk_bf16(acc[(2 * k + 1) & (NB - 1)][nb][2 * jj], acc[(2 * k + 1) & (NB - 1)][nb][2 * jj + 1]); \
                                     }                                                                                  \
                                     if (relu) { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) ow[jj] = q_pk_max_i16(ow[jj], 0u); } \
+                                    if (a.aux) { ow[0] = q_relu_mask(ow[0], mm[k][nb].x); ow[1] = q_relu_mask(ow[1], mm[k][nb].y);  \
+                                                 ow[2] = q_relu_mask(ow[2], mm[k][nb].z); ow[3] = q_relu_mask(ow[3], mm[k][nb].w); } \
                                     if (4 * k + q < CDc) *QGP(qu32x4_t, d + k * 1024) = qu32x4_t{ow[0], ow[1], ow[2], ow[3]}; \
                                 }                                                                                      \
                             }                                                                                          \
@@ -449,12 +477,13 @@ extern "C" int vsr_debug_read_clk7(unsigned long long* host_out) {     // [256 w
 }
 #endif
 
-// Eligibility (bf16, 7x7, one pixel-major source at unit step, no residual / mask operand) is checked here; the caller falls
+// Eligibility (bf16, 7x7, one pixel-major source at unit step, no residual operand; mask: ReLU' of a stored activation) is checked here; the caller falls
 // back to the generic kernel on VSR_ERR_UNSUPPORTED.  cin: channels per source pixel; cop: rows per tap of the packed weights.
 int vsr_launch_conv7x7_persist(const ConvArgs& a, int cin, int cop, int epi, int num_cus, hipStream_t st) {
     if (a.nz != 1 || a.in_step != 1 || a.src_oy[0] != 0 || a.src_ox[0] != 0 || a.Hs != a.H || a.Ws != a.W || !a.src[0]) return VSR_ERR_UNSUPPORTED;
     if (a.out_step != 1 || a.out_oy[0] != 0 || a.out_ox[0] != 0 || a.Hd != a.H || a.Wd != a.W) return VSR_ERR_UNSUPPORTED;
-    if (a.res[0] || a.aux[0] || a.base_lr || (a.act != ACT_NONE && a.act != ACT_RELU) || a.cout_real < 1) return VSR_ERR_UNSUPPORTED;
+    if (a.res[0] || a.base_lr || (a.act != ACT_NONE && a.act != ACT_RELU) || a.cout_real < 1) return VSR_ERR_UNSUPPORTED;
+    if (a.aux[0] && (a.mask_mode != MASK_RELU || epi != EPI_NHWC)) return VSR_ERR_UNSUPPORTED;
     if (pm_image_elems(QTHH + 2, a.W, cin) * 2 > 0x7fffffffLL || (long long)49 * cop * cin * 2 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;
     if (epi == EPI_PLANAR) {
         if (a.cout_real > 4 || cop < 16 || cin != 16) return VSR_ERR_UNSUPPORTED;
@@ -469,6 +498,7 @@ int vsr_launch_conv7x7_persist(const ConvArgs& a, int cin, int cop, int epi, int
     C7_CASE(32, 4)      // 32 -> 64
     C7_CASE(64, 2)      // 64 -> 32
     C7_CASE(32, 1)      // 32 -> 16
+    C7_CASE(16, 1)      // data gradient of 16 -> 2 (16 padded rows -> 16 channels)
 #undef C7_CASE
     return VSR_ERR_UNSUPPORTED;
 }

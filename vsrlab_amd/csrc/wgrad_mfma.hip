@@ -704,6 +704,8 @@ extern "C" int vsr_debug_read_wclk(unsigned long long* host_out) {
     X(7, 32, false, 16, false)        /* 32->16 */ \
     X(7, 16, false, 16, false)        /* 16->2 (dY = masked flow gradient, 16-channel padded) */
 
+int vsr_launch_wgrad7x7_pc(int cx, int cout, const WgradArgs& a, int max_slabs, int* nslabs, hipStream_t st);   // wgrad7x7_pc.hip
+
 // slab layout helper shared with the engine
 void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride) {
     const int ncb = cout >= 32 ? cout / 32 : 1, nib = cx >= 32 ? cx / 32 : 1;
@@ -722,6 +724,13 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
             *nslabs = nwg / 2;                                 // one 512-thread workgroup per CU, one slab each
             return launch_wgrad_pc(a, nwg / 2, st);
         }
+    }
+    // SPyNet's 7x7 layers (train_flow): producer / consumer kernel, all seven kernel rows in one launch (wgrad7x7_pc.hip); the
+    // caller's nwg is also what its slab buffer holds of this shape's partials
+    if (!vsr_env().generic_wgrad && dtype == VSR_BF16 && ks == 7 && !x_planar && !dy_planar) {
+        const int rc = vsr_launch_wgrad7x7_pc(cx, cout, a, nwg, nslabs, st);
+        if (rc != VSR_ERR_UNSUPPORTED) return rc;
+        *nslabs = nwg;
     }
 #define X(KS, CX, XP, COUT, DP)                                                                        \
     if (ks == KS && cx == CX && (x_planar != 0) == XP && cout == COUT && (dy_planar != 0) == DP) {    \
