@@ -12,6 +12,7 @@ timeout -k 10 200 python tools/ab_wgrad.py 5 libvsrlab_hip.so libvsrlab_hip_wgra
 timeout -k 10 200 python tools/ab_c7.py 3 libvsrlab_hip.so libvsrlab_hip_conv7x7_persist_abl0.so > $O/clock_c7.log 2>&1 &&
 timeout -k 10 250 python bench.py --no-cpu-baseline --arena diet > $O/bench_diet.json 2> $O/bench_diet.err &&
 timeout -k 10 300 python bench.py --no-cpu-baseline --arena diet --clips 2 --steps 3 > $O/bench_diet_2clips.json 2> $O/bench_diet_2clips.err &&
+timeout -k 10 250 python bench.py --no-cpu-baseline --train-flow > $O/bench_train_flow.json 2> $O/bench_train_flow.err &&
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gan -o gan -- python3 tools/bench_gan.py 1 > $O/gan_prof.log 2>&1 &&
 timeout -k 10 200 python tools/bench_gan.py 3 > $O/gan.log 2>&1; tail -1 $O/gan.log
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
