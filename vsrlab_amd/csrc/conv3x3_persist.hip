@@ -322,6 +322,17 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         f32x4_t bvec[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) bvec[mb] = *reinterpret_cast<const f32x4_t*>(smem + BIAS_OFF + (mb * 16 + 4 * q) * 4);
+        // The residual is added ON THE MATRIX CORES (r03): the 16-byte residual piece a lane prefetches (chunk 4k + q of its pixel) is
+        // exactly a B fragment of a K step over the 32 channels of pieces k, and "+ residual" is one more MFMA per accumulator with a
+        // 0 / 1 selection matrix as A: row r of block mb is channel pm_acc_chan(mb, r) = k group r >> 2, element 4 (mb & 1) + (r & 3) of
+        // that step.  16 MFMAs (256 cycles) replace 64 unpacks + 64 adds per tile and wave (512 issue cycles); fp32 accumulation of
+        // 1.0 x bf16 is the same single rounding as the v_add_f32 it replaces.
+        bf16x8_t idA[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) idA[hb][j] = (bf16_t)((q == (l15 >> 2) && j == 4 * hb + (l15 & 3)) ? 1.f : 0.f);
+        constexpr bool RES_MFMA = HAS_RES && !ABL(4);
 
         // ---------------------------------------------------------------------------------------------------------------
         // Pipelined tile loop of the hot epilogues (r03).  The 64 output channels of a tile are accumulated in two PHASES of 18
@@ -591,6 +602,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             // per bias+skip launch).  One explicit wait here (the builtin: hipcc's scoreboard then knows the queue is empty)
             // covers the operands; the stores after it are never waited for inside the tile.
             if (HAS_RES || MASK != MASK_NONE) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) alone
+            if constexpr (RES_MFMA) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(idA[mb & 1], __builtin_bit_cast(bf16x8_t, rr[mb >> 1][nb]), acc[mb][nb], 0, 0, 0);
+            }
             // Sign bits of the tile: the lane's 64 outputs are 32 packed words wd = (4k + nb) * 4 + jj (channels 2jj, 2jj+1 of the
             // piece); word wd owns bits (wd & 15) [even channel] and 16 + (wd & 15) [odd channel] of sout[wd >> 4].
             unsigned sout[2] = {0u, 0u};
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) v[j] = p_act<ACT>(v[j], slope);
-                            if (HAS_RES) {
+                            if (HAS_RES && !(RES_MFMA && ACT == ACT_NONE)) {
                                 const unsigned rw[4] = {rr[k][nb].x, rr[k][nb].y, rr[k][nb].z, rr[k][nb].w};
 #pragma unroll
                                 for (int jj = 0; jj < 4; ++jj) { v[2 * jj] += bf_lo(rw[jj]); v[2 * jj + 1] += bf_hi(rw[jj]); }
