@@ -42,8 +42,6 @@ extern "C" {
 #define VSR_STATUS_HIP (-3)
 #define VSR_STATUS_WORKSPACE (-4)
 
-/* 3.  History: 2 = fixed-order Charbonnier reduction (scratch argument); 3 = VsrBasicVSRDesc.arena_mode (diet training arena),
- * vsr_spynet_forward_ex(need_backward) and vsr_spynet_backward_ex(last_relu, per-level cotangents).                     */
 int vsr_abi_version(void);
 const char* vsr_status_string(int status);
 
