@@ -2,8 +2,11 @@
 // streaming problem, not a GEMM.  Dedicated bf16 kernels for the HR tail of the backward pass (the generic tiled
 // kernel pads 3 channels to 16/32 and synchronises per tap: 0.9 ms per frame at 2160x3840 against an HBM floor of ~0.45).
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
+
+__device__ float g_lt_zero[4];
 
 struct __attribute__((aligned(8))) bf4_t { bf16_t v[4]; };
 
@@ -28,6 +31,9 @@ __device__ __forceinline__ void hr_barrier() {
 // (k, nb), packed word jj: bits 4 nb + jj and 16 + 4 nb + jj of word k): this kernel uses the SAME tile decomposition, channel
 // order and lane -> pixel permutation, so a lane reads its own 64 bits (4 MB per 540p-sized tile set) instead of 8 x 16 bytes
 // of the bf16 activation (the whole 1.06 GB C0 at HR).
+// MODE: where the activation-gradient mask comes from -- 0 none, 1 the bf16 activation `aux`, 2 its sign bits (compile-time: with run-time
+// branches on the two pointers hipcc put a vmcnt(0) at the top of every tile, i.e. waited for the previous tile's output stores)
+template <int MODE>
 __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restrict__ dsr, long long dsr_nstride,
                                                             const float* __restrict__ w, const bf16_t* __restrict__ aux,
                                                             const uint2* __restrict__ sign_bits, float neg,
@@ -57,40 +63,51 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
     }
     (void)mask_mode;
 
-    // haloed dSR tile -> LDS (zeros outside the image) in two halves: the global loads are issued BEFORE a tile's MFMAs and
-    // epilogue, the LDS writes after them, so the load latency is covered by the tile's own work (vmcnt counts the younger
-    // output stores too: hipcc waits for the loads only).  r02: 580 -> 440 us per 2160x3840 frame together with hr_barrier().
-    constexpr int ST_N = (3 * LT_PL + LT_NT - 1) / LT_NT;
-    auto stage_load = [&](int t, float (&v)[ST_N]) {
+    // haloed dSR tile -> LDS (zeros outside the image) by LDS-DMA, 4 bytes per lane (the 34-float rows of a plane start 3 floats before
+    // a 16-byte boundary), one whole tile ahead into the other buffer: 16 instructions of 64 floats per tile, 4 per wave.  r03: the
+    // register-staged form waited, at its LDS write behind the tile's 8 output stores, for those stores (vmcnt counts in order), the B
+    // gather had a branch and an lgkmcnt(0) per element (32 exposed LDS round trips per tile), and the epilogue branched per pixel block.
+    int srel[4];                                             // source byte offset of this lane's float of piece w4 + 4 i from the tile origin
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (w4 + 4 * i) * 64 + lane;
+        const int c = e / LT_PL, rem = e - c * LT_PL, yy = rem / LT_RS, xx = rem - yy * LT_RS;
+        srel[i] = (int)(((long long)c * plane + (long long)(yy - 1) * W + (xx - 1)) * 4);
+    }
+    const char* zsrc = reinterpret_cast<const char*>(g_lt_zero);
+    auto stage_dma = [&](int t, int b) {
         const int n = t / (ntx * nty), r = t - n * (ntx * nty);
         const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
-        const float* base = dsr + (long long)n * dsr_nstride;
+        const char* org = reinterpret_cast<const char*>(dsr + (long long)n * dsr_nstride + (long long)ty0 * W + tx0);
+        // straight-line: exactly 4 vector-memory instructions per call, so that hipcc can count them (with a branch per border tile in
+        // here it waited with vmcnt(0) for the sign-bit load in front of them, i.e. for this DMA itself)
 #pragma unroll
-        for (int i = 0; i < ST_N; ++i) {
-            const int e = tid + i * LT_NT;
-            const int c = e / LT_PL, rem = e - c * LT_PL;
-            const int yy = rem / LT_RS, xx = rem - yy * LT_RS;
+        for (int i = 0; i < 4; ++i) {
+            const int e = (w4 + 4 * i) * 64 + lane;
+            const int c = e / LT_PL, rem = e - c * LT_PL, yy = rem / LT_RS, xx = rem - yy * LT_RS;
             const int vy = ty0 + yy - 1, vx = tx0 + xx - 1;
-            v[i] = (e < 3 * LT_PL && vy >= 0 && vy < H && vx >= 0 && vx < W) ? base[c * plane + (long long)vy * W + vx] : 0.f;
+            const char* sp = (vy >= 0 && vy < H && vx >= 0 && vx < W) ? org + srel[i] : zsrc;
+            if (e < 3 * LT_PL)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                                 (__attribute__((address_space(3))) void*)(&tile[b][(w4 + 4 * i) * 64]), 4, 0, 0);
         }
     };
-    auto stage_store = [&](const float (&v)[ST_N], int buf) {
+    // B gather addresses: element j of this lane's fragment is float boff[j] of the tile (k = 8 q + j >= 27: any float, its A column is zero)
+    unsigned gaddr[8];
 #pragma unroll
-        for (int i = 0; i < ST_N; ++i) {
-            const int e = tid + i * LT_NT;
-            if (e < 3 * LT_PL) tile[buf][e] = v[i];
-        }
-    };
+    for (int j = 0; j < 8; ++j) gaddr[j] = (unsigned)(((boff[j] >= 0 ? boff[j] : 0) + (2 * w4) * LT_RS + i15) * 4);
+    const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(&tile[0][0]);     // LDS byte offset of the tile buffers
 
     int t = blockIdx.x, buf = 0;
-    float sv[ST_N];
-    if (t < total) { stage_load(t, sv); stage_store(sv, 0); }
+    if (t < total) stage_dma(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (; t < total; t += gridDim.x) {
         const int n = t / (ntx * nty), r = t - n * (ntx * nty);
         const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
         const long long obase = (long long)n * pm_image_elems(H, W, 64) + pm_off(ty0, tx0, 0, W, 64);
-        // mask operands first: their latency hides behind the staging of the next tile and the MFMAs
+        const bool full = ty0 + LT_H <= H && tx0 + LT_W <= W;
+        // mask operands first (older than the DMA below: waiting for them does not wait for the DMA)
         uint4 mm[2][4];
         bool ok[4];
         int loff[4];
@@ -99,43 +116,62 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
             const int row = 2 * w4 + (nb >> 1), px = (nb & 1) * 16 + i15;
             ok[nb] = ty0 + row < H && tx0 + px < W;
             loff[nb] = (row * pm_ws(W) * 8 + q) * 256 + px * 8;
-            if (aux && !sign_bits && ok[nb]) {
+            if (MODE == 1 && ok[nb]) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) mm[k][nb] = *reinterpret_cast<const uint4*>(aux + obase + loff[nb] + k * 1024);
             }
         }
-        uint2 sb = make_uint2(0u, 0u);
-        if (sign_bits) sb = sign_bits[(long long)t * 256 + w4 * 64 + lane];
+        // the 64 sign bits of this lane's outputs: requested by inline asm and waited for by hand below -- four DMA instructions follow it
+        // (behind exec-mask branches hipcc cannot count), and its own wait in front of the first use was a vmcnt(0), i.e. for that DMA
+        typedef __attribute__((ext_vector_type(2))) unsigned sb2_t;
+        sb2_t sbv = {0u, 0u};
+        if (MODE == 2) {
+            const auto* sp = (const __attribute__((address_space(1))) sb2_t*)(sign_bits + ((long long)t * 256 + w4 * 64 + lane));
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sbv) : "v"(sp) : "memory");
+        }
         const int tn = t + gridDim.x;
-        if (tn < total) stage_load(tn, sv);                  // lands during this tile's MFMAs / epilogue
-        // B[k][n = pixel i] for this wave's 4 pixel blocks, then 16 MFMAs
+        stage_dma(tn < total ? tn : t, buf ^ 1);             // lands during this tile's work (the walk's last tile re-stages itself: no branch)
+        // B[k][n = pixel i] for this wave's 4 pixel blocks (32 ds_read_b32 in flight, inline asm: hipcc would drain the DMA in front of a
+        // plain LDS read), then 16 MFMAs
         f32x4_t acc[4][4];
+        {
+            const unsigned tb = tile_lds + (unsigned)(buf * 3 * LT_PL * 4);
+            float gv[4][8];
+#define LD_G(nb_, j_) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gv[nb_][j_]) : "v"(tb + gaddr[j_]), "n"((((nb_) >> 1) * LT_RS + ((nb_) & 1) * 16) * 4))
+#define LD_G8(nb_) LD_G(nb_, 0); LD_G(nb_, 1); LD_G(nb_, 2); LD_G(nb_, 3); LD_G(nb_, 4); LD_G(nb_, 5); LD_G(nb_, 6); LD_G(nb_, 7);
+            LD_G8(0) LD_G8(1) LD_G8(2) LD_G8(3)
+#undef LD_G8
+#undef LD_G
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int row = 2 * w4 + (nb >> 1), px = (nb & 1) * 16 + i15;
-            const float* tp = tile[buf] + row * LT_RS + px;
-            bf16x8_t fb;
+            for (int nb = 0; nb < 4; ++nb) {
+                asm volatile("" : "+v"(gv[nb][0]), "+v"(gv[nb][1]), "+v"(gv[nb][2]), "+v"(gv[nb][3]), "+v"(gv[nb][4]), "+v"(gv[nb][5]), "+v"(gv[nb][6]), "+v"(gv[nb][7]));
+                bf16x8_t fb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fb[j] = (bf16_t)(boff[j] >= 0 ? tp[boff[j]] : 0.f);
+                for (int j = 0; j < 8; ++j) fb[j] = (bf16_t)gv[nb][j];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mb], fb, z, 0, 0, 0);
+                for (int mb = 0; mb < 4; ++mb) {
+                    f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mb], fb, z, 0, 0, 0);
+                }
             }
         }
+        if (MODE == 2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); asm volatile("" : "+v"(sbv)); }     // the sign bits are here; the 4 DMA pieces may be in flight
+        const uint2 sb = make_uint2(sbv.x, sbv.y);
+        auto epilogue = [&](auto FULL) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            if (!ok[nb]) continue;
+            if (!(decltype(FULL)::value || ok[nb])) continue;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = acc[2 * k][nb][j]; v[4 + j] = acc[2 * k + 1][nb][j]; }
-                if (sign_bits) {
+                if (MODE == 2) {
                     const unsigned wbits = k ? sb.y : sb.x;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] *= ((wbits >> (4 * nb + (j >> 1) + 16 * (j & 1))) & 1u) ? 1.f : neg;
-                } else if (aux) {
+                } else if (MODE == 1) {
                     const unsigned mw[4] = {mm[k][nb].x, mm[k][nb].y, mm[k][nb].z, mm[k][nb].w};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -149,7 +185,14 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
                 *reinterpret_cast<bf16x8_t*>(dst + obase + loff[nb] + k * 1024) = o;
             }
         }
-        if (tn < total) stage_store(sv, buf ^ 1);            // the other buffer: nobody reads it during this tile
+        };
+        if (full) {
+            epilogue(std::true_type{});
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the 8 stores of this tile may stay in flight: the DMA in front of them has landed
+        } else {
+            epilogue(std::false_type{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         hr_barrier();                                        // the next tile is staged; this one is consumed
         buf ^= 1;
     }
@@ -187,6 +230,11 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int i15 = lane & 15, q = lane >> 4;
+    // pixel of a 16-pixel block that lane column i15 works on: the persistent conv kernel's permutation (even pixels on lanes 4-11, odd ones
+    // on 0-3 / 12-15), which makes every lane group of a ds_read_b128 hit 16 distinct bank groups (r03 PMC: 44 % of this kernel's LDS
+    // cycles were bank conflicts with pixel = lane; 437 -> 424 us per 2160x3840 frame.  A ring of three tile buffers on top of it measured
+    // 427 us: with the conflicts gone the consumers, not the DMA, set the tile time)
+    const int px15 = (i15 >= 4 && i15 < 12) ? 2 * (i15 - 4) : (i15 < 4 ? 2 * i15 + 1 : 2 * (i15 - 8) + 1);
     const int ntx = cdiv(a.W, LT_W), nty = cdiv(a.H, LT_H);
     const int total = a.N * ntx * nty;
     const TileWalk walk = xcd_tile_walk(total, blockIdx.x, gridDim.x);
@@ -247,18 +295,50 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
                 fa[tap][kk] = *reinterpret_cast<const bf16x8_t*>(wp + ((tap * 32 + i15) * 64 + kk * 32 + 8 * q));
     }
     const long long plane = (long long)a.Hd * a.Wd;
+    // The BasicVSR case (conv_last.2 + bilinear x4 skip, 3 channels, an LR frame of exactly H/4 x W/4) without per-tile divisions,
+    // float index arithmetic or per-channel branches (r03: the tile time of this kernel is set by its consumers).  For d = 4 m + r,
+    // (d + 0.5) / 4 - 0.5 = m + (r - 1.5) / 4: source index m - 1 (r < 2) or m, weight 0.625 / 0.875 / 0.125 / 0.375 -- exactly what
+    // hr_bil4 computes in fp32; tile origins are multiples of 8 and 32, so r and the weight are per-lane constants.
+    const int oyr = 2 * w4 + (q >> 1), oxr = (q & 1) * 16 + px15;
+    const int yk = (oyr >> 2) - ((oyr & 3) < 2 ? 1 : 0), xk = (oxr >> 2) - ((oxr & 3) < 2 ? 1 : 0);
+    const float wq[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+    const float lyc = wq[oyr & 3], lxc = wq[oxr & 3];
+    const bool fast = a.base_lr && !a.pres && a.cout_real == 3 && a.base_h * 4 == a.H && a.base_w * 4 == a.W;
+    float bs[3] = {0.f, 0.f, 0.f};
+    if (fast && a.bias) { bs[0] = a.bias[0]; bs[1] = a.bias[1]; bs[2] = a.bias[2]; }
+    const long long lr_plane = (long long)a.base_h * a.base_w;
+    int tn = walk.first / (ntx * nty), tyi, txi;               // image, tile row, tile column of the walk, advanced by adds and carries
+    { const int r0 = walk.first - tn * (ntx * nty); tyi = r0 / ntx; txi = r0 - tyi * ntx; }
+    const int sn = walk.stride / (ntx * nty), sty = (walk.stride - sn * (ntx * nty)) / ntx, stx = walk.stride - sn * (ntx * nty) - sty * ntx;
     __syncthreads();                                         // the first tile is in LDS
     int cur = 0;
     for (int t = walk.first; t < walk.end; t += walk.stride) {
-        const int n = t / (ntx * nty), r = t - n * (ntx * nty);
-        const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+        const int n = tn, ty0 = tyi * LT_H, tx0 = txi * LT_W;
+        txi += stx; if (txi >= ntx) { txi -= ntx; ++tyi; }
+        tyi += sty; if (tyi >= nty) { tyi -= nty; ++tn; }
+        tn += sn;
         // epilogue operands first (their latency hides behind the MFMAs).  The accumulator rows that matter (m = 0..3)
         // sit in lanes 0-15 only; after the K loop they are broadcast so that lane group q finishes pixel block nb = q:
         // all 64 lanes load / store, one pixel each.
-        const int oy = ty0 + 2 * w4 + (q >> 1), ox = tx0 + (q & 1) * 16 + i15;
+        const int oy = ty0 + oyr, ox = tx0 + oxr;
         const bool ok = oy < a.H && ox < a.W;
         float add[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
+        if (fast) {
+            int y0 = (ty0 >> 2) + yk, x0 = (tx0 >> 2) + xk;
+            float ly = lyc, lx = lxc;
+            if (y0 < 0) { y0 = 0; ly = 0.f; }
+            if (x0 < 0) { x0 = 0; lx = 0.f; }
+            if (!ok) { y0 = 0; x0 = 0; }                     // lanes of an outside pixel load the frame's first pixel and store nothing
+            const int y1 = y0 + (y0 < a.base_h - 1 ? 1 : 0), x1 = x0 + (x0 < a.base_w - 1 ? 1 : 0);
+            const float* bp = a.base_lr + (long long)n * a.base_nstride;
+            const int o00 = y0 * a.base_w + x0, o01 = y0 * a.base_w + x1, o10 = y1 * a.base_w + x0, o11 = y1 * a.base_w + x1;
+            float lv[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lv[c][0] = bp[c * lr_plane + o00]; lv[c][1] = bp[c * lr_plane + o01]; lv[c][2] = bp[c * lr_plane + o10]; lv[c][3] = bp[c * lr_plane + o11]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                add[c] = bs[c] + ((1.f - ly) * ((1.f - lx) * lv[c][0] + lx * lv[c][1]) + ly * ((1.f - lx) * lv[c][2] + lx * lv[c][3]));
+        } else if (ok) {
             int y0 = 0, y1 = 0, x0 = 0, x1 = 0; float ly = 0.f, lx = 0.f;
             if (a.base_lr) { hr_bil4(oy, a.base_h, y0, y1, ly); hr_bil4(ox, a.base_w, x0, x1, lx); }
 #pragma unroll
@@ -278,17 +358,32 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
         f32x4_t acc[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const char* tb = tiles + cur * FP_TILE + (2 * w4) * FP_ROW + q * FP_CH + i15 * 16;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(tb + ((nb >> 1) + tap / 3) * FP_ROW + kk * 4 * FP_CH +
-                                                                            ((nb & 1) * 16 + tap % 3) * 16);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tap][kk], fb, acc[nb], 0, 0, 0);
-                }
+        // K loop in 8 groups g = (tile row R = g >> 1 of the wave's 4 haloed rows, channel half kk = g & 1): the group's 6 B fragments
+        // (pixels kx, 16 + kx) serve the output rows rowsel = 0, 1 with ky = R - rowsel: 6 or 12 MFMAs.  The fragments of group g + 1 are
+        // requested (inline asm: hipcc puts an lgkmcnt(0) in front of almost every MFMA of a plain loop -- 22 exposed LDS round trips
+        // per tile, r03) behind the first MFMAs of group g into the other register set.
+        const unsigned tbu = (unsigned)(cur * FP_TILE + (2 * w4) * FP_ROW + q * FP_CH + px15 * 16);   // the dynamic LDS segment starts at 0
+        bf16x8_t fbq[2][6];
+#define CP_DSR(dst_, imm_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(tbu), "n"(imm_))
+#define CP_LOAD1(g_, i_) if constexpr ((g_) < 8) { CP_DSR(fbq[(g_) & 1][i_], ((g_) >> 1) * FP_ROW + ((g_) & 1) * 4 * FP_CH + (((i_) / 3) * 16 + (i_) % 3) * 16); }
+#define CP_SB __builtin_amdgcn_sched_barrier(0);
+        // MFMA m (0..11) of group g: rowsel = m / 6, half = (m / 3) & 1, kx = m % 3
+#define CP_MFMA(g_, m_)                                                                                                \
+        { constexpr int R_ = (g_) >> 1, kk_ = (g_) & 1, rs_ = (m_) / 6, hf_ = ((m_) / 3) & 1, kx_ = (m_) % 3, ky_ = R_ - rs_;  \
+          if constexpr (ky_ >= 0 && ky_ <= 2)                                                                           \
+              acc[rs_ * 2 + hf_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(ky_ < 0 ? 0 : ky_ > 2 ? 2 : ky_) * 3 + kx_][kk_], fbq[(g_) & 1][hf_ * 3 + kx_], acc[rs_ * 2 + hf_], 0, 0, 0); }
+#define CP_GROUP(g_)                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); CP_SB                                                      \
+        CP_MFMA(g_, 0) CP_MFMA(g_, 6) CP_SB CP_LOAD1((g_) + 1, 0) CP_SB CP_MFMA(g_, 1) CP_MFMA(g_, 7) CP_SB CP_LOAD1((g_) + 1, 1) CP_SB  \
+        CP_MFMA(g_, 2) CP_MFMA(g_, 8) CP_SB CP_LOAD1((g_) + 1, 2) CP_SB CP_MFMA(g_, 3) CP_MFMA(g_, 9) CP_SB CP_LOAD1((g_) + 1, 3) CP_SB  \
+        CP_MFMA(g_, 4) CP_MFMA(g_, 10) CP_SB CP_LOAD1((g_) + 1, 4) CP_SB CP_MFMA(g_, 5) CP_MFMA(g_, 11) CP_SB CP_LOAD1((g_) + 1, 5) CP_SB
+        CP_SB CP_LOAD1(0, 0) CP_LOAD1(0, 1) CP_LOAD1(0, 2) CP_LOAD1(0, 3) CP_LOAD1(0, 4) CP_LOAD1(0, 5)
+        CP_GROUP(0) CP_GROUP(1) CP_GROUP(2) CP_GROUP(3) CP_GROUP(4) CP_GROUP(5) CP_GROUP(6) CP_GROUP(7)
+#undef CP_GROUP
+#undef CP_MFMA
+#undef CP_SB
+#undef CP_LOAD1
+#undef CP_DSR
         float* dst = reinterpret_cast<float*>(a.dst[0]) + (long long)n * a.dst_nstride + (long long)oy * a.Wd + ox;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -474,48 +569,72 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t
         const char* src = reinterpret_cast<const char*>(x);
         const char* zsrc = reinterpret_cast<const char*>(g_fp_zero_chunk);
         const int WSs = pm_ws(W);
-        auto issue = [&](int tile, int buf) {
-            const int n = tile / (ntx * nty), r = tile - n * (ntx * nty);
-            const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
-            const char* org = src + ((long long)n * pm_image_elems(H, W, 64) + pm_off(ty0, tx0, 0, W, 64)) * 2;
+        // rel[i]: source byte offset of this lane's slot of piece w4 + 4 i from the tile origin (per-lane constants; r03: computed per
+        // piece and tile before, hipcc hoisted the invariant parts and spilled them -- two 16-byte scratch round trips per tile in the
+        // producers' loop); (image, tile row, tile column) advance by adds and carries
+        int rel[LW_NPIECE_W];
+#pragma unroll
+        for (int i = 0; i < LW_NPIECE_W; ++i) {
+            const int idx = (w4 + 4 * i) * 64 + lane;        // LDS slot = [row ty][chunk c][36 slots tx] x 16 B
+            const int ty = idx / (8 * LW_XS), rem = idx - ty * (8 * LW_XS);
+            const int c = rem / LW_XS, dx = rem - c * LW_XS - 1;
+            rel[i] = ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+        }
+        const long long img_bytes = pm_image_elems(H, W, 64) * 2;
+        auto issue = [&](int n, int tyi, int txi, int buf) {
+            const int ty0 = tyi * LT_H, tx0 = txi * LT_W;
+            const char* org = src + (long long)n * img_bytes + pm_off(ty0, tx0, 0, W, 64) * 2;
             char* dstb = tiles + buf * LW_TILE;
+            const bool interior = ty0 >= 1 && ty0 + LT_H < H && tx0 >= 1 && tx0 + LT_W < W;      // wave-uniform
 #pragma unroll
             for (int i = 0; i < LW_NPIECE_W; ++i) {
                 const int piece = w4 + 4 * i;
                 if (piece >= LW_NPIECE) break;
-                const int idx = piece * 64 + lane;           // LDS slot = [row ty][chunk c][36 slots tx] x 16 B
-                const int ty = idx / (8 * LW_XS), rem = idx - ty * (8 * LW_XS);
-                const int c = rem / LW_XS, tx = rem - c * LW_XS;
-                const int dx = tx - 1;
-                const int vy = ty0 + ty - 1, vx = tx0 + dx;
-                const char* sp = org + ((((ty - 1) * WSs + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
-                if (!(tx < LT_W + 2 && vy >= 0 && vy < H && vx >= 0 && vx < W)) sp = zsrc;
+                const int idx = piece * 64 + lane;
+                const int ty = idx / (8 * LW_XS), tx = (idx - ty * (8 * LW_XS)) % LW_XS;
+                const char* sp = org + rel[i];
+                if (tx >= LT_W + 2) sp = zsrc;               // pad slots
+                else if (!interior) {
+                    const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+                    if (!(vy >= 0 && vy < H && vx >= 0 && vx < W)) sp = zsrc;
+                }
                 FP_GLDS16(sp, dstb + piece * 1024);
             }
         };
         // dY tile [co (3)][8 rows][32 px] fp32 = 3 pieces of 1 KiB: piece c on producer wave c + 1 (those waves carry 11 X pieces, so every
         // wave issues 12 DMA instructions per tile).  W is a multiple of 4 here, so a 16-byte chunk is inside the image or outside it.
-        auto issue_dy = [&](int tile, int buf) {
+        auto issue_dy = [&](int n, int tyi, int txi, int buf) {
             if (w4 == 0) return;
-            const int n = tile / (ntx * nty), r = tile - n * (ntx * nty);
-            const int ty0 = (r / ntx) * LT_H, tx0 = (r % ntx) * LT_W;
+            const int ty0 = tyi * LT_H, tx0 = txi * LT_W;
             const int row = lane >> 3, xc = (lane & 7) * 4;
             const float* sp = dy + (long long)n * dy_nstride + (long long)(w4 - 1) * plane + (long long)(ty0 + row) * W + tx0 + xc;
             const char* spc = (ty0 + row < H && tx0 + xc < W) ? reinterpret_cast<const char*>(sp) : zsrc;
             FP_GLDS16(spc, tiles + 3 * LW_TILE + buf * LW_DY + (w4 - 1) * 1024);
         };
+        struct { int T, n, ty, tx; } it;
+        const int per = ntx * nty;
+        { int r0 = walk.first; it.T = r0; it.n = r0 / per; r0 -= it.n * per; it.ty = r0 / ntx; it.tx = r0 - it.ty * ntx; }
+        const int sn = walk.stride / per, sty = (walk.stride - sn * per) / ntx, stx = walk.stride - sn * per - sty * ntx;
+        auto advance = [&]() {
+            it.T += walk.stride;
+            it.tx += stx; if (it.tx >= ntx) { it.tx -= ntx; ++it.ty; }
+            it.ty += sty; if (it.ty >= nty) { it.ty -= nty; ++it.n; }
+            it.n += sn;
+        };
         // ring of three tile buffers, DMA two tiles ahead (the tile's work is far shorter than the loaded memory latency: two tiles in
         // flight instead of one); at the end of tile i only tile i+1 must have landed: the 12 pieces of tile i+2 stay in flight
-        int cur = 0, tile = walk.first;
-        if (tile < walk.end) { issue(tile, 0); issue_dy(tile, 0); }
-        if (tile + walk.stride < walk.end) { issue(tile + walk.stride, 1); issue_dy(tile + walk.stride, 1); }
+        int cur = 0;                                         // `it` = the tile two ahead of the consumers once the loop runs
+        if (it.T < walk.end) { issue(it.n, it.ty, it.tx, 0); issue_dy(it.n, it.ty, it.tx, 0); }
+        advance();
+        if (it.T < walk.end) { issue(it.n, it.ty, it.tx, 1); issue_dy(it.n, it.ty, it.tx, 1); }
+        advance();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (; tile < walk.end; tile += walk.stride) {
-            const int next2 = tile + 2 * walk.stride;
-            if (next2 < walk.end) {
+        for (int tile = walk.first; tile < walk.end; tile += walk.stride) {
+            if (it.T < walk.end) {
                 const int b2 = cur == 0 ? 2 : cur - 1;
-                issue(next2, b2); issue_dy(next2, b2);
+                issue(it.n, it.ty, it.tx, b2); issue_dy(it.n, it.ty, it.tx, b2);
+                advance();
                 asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -555,19 +674,34 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t
                 for (int j = 0; j < 8; ++j) { const float vv = i15 < 3 ? v[j] : 0.f; fb[rr][j] = (bf16_t)vv; bsum += vv; }
             }
         }
-        const char* tb = tiles + cur * LW_TILE + abase;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const char* pa = tb + (2 * w4 + rr + tap / 3) * LW_ROW + mb * 2 * (LW_XS * 16) + (tap % 3) * 16;
-                    union { s16x4_t s[2]; bf16x8_t b; } u;
-                    u.s[0] = hr_tr_read(pa);
-                    u.s[1] = hr_tr_read(pa + 64);
-                    acc[tap][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.b, fb[rr], acc[tap][mb], 0, 0, 0);
-                }
+        // K loop in 8 groups g = (X row R = g >> 1 of the wave's 4 haloed rows, ci-block pair mp = g & 1): the group's 6 A fragments (ci
+        // block 2 mp + i / 3, tap column kx = i % 3; two transposing reads each) serve the output rows rr = 0, 1 with ky = R - rr: 6 or 12
+        // MFMAs.  The reads of group g + 1 go out behind the MFMAs of group g into the other register set (inline asm; the plain loop
+        // had an lgkmcnt(0) in front of 40 of a tile's 72 MFMAs and spilled two accumulator blocks, r03).
+        const unsigned tbu = (unsigned)(cur * LW_TILE + abase + (2 * w4) * LW_ROW);      // the dynamic LDS segment starts at 0
+        union { s16x4_t s[2]; bf16x8_t b; } fq[2][6];
+#define LW_TRR(dst_, imm_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst_) : "v"(tbu), "n"(imm_))
+#define LW_LOAD1(g_, i_) if constexpr ((g_) < 8) {                                                                     \
+            LW_TRR(fq[(g_) & 1][i_].s[0], ((g_) >> 1) * LW_ROW + (2 * ((g_) & 1) + (i_) / 3) * 2 * (LW_XS * 16) + ((i_) % 3) * 16);       \
+            LW_TRR(fq[(g_) & 1][i_].s[1], ((g_) >> 1) * LW_ROW + (2 * ((g_) & 1) + (i_) / 3) * 2 * (LW_XS * 16) + ((i_) % 3) * 16 + 64); }
+#define LW_SB __builtin_amdgcn_sched_barrier(0);
+        // MFMA m (0..11) of group g: rr = m / 6, fragment i = m % 6
+#define LW_MFMA(g_, m_)                                                                                                \
+        { constexpr int R_ = (g_) >> 1, rr_ = (m_) / 6, i_ = (m_) % 6, ky_ = R_ - rr_, mb_ = 2 * ((g_) & 1) + i_ / 3, kyc_ = ky_ < 0 ? 0 : ky_ > 2 ? 2 : ky_;  \
+          if constexpr (ky_ >= 0 && ky_ <= 2)                                                                           \
+              acc[kyc_ * 3 + i_ % 3][mb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[(g_) & 1][i_].b, fb[rr_], acc[kyc_ * 3 + i_ % 3][mb_], 0, 0, 0); }
+#define LW_GROUP(g_)                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LW_SB                                                      \
+        LW_MFMA(g_, 0) LW_MFMA(g_, 6) LW_SB LW_LOAD1((g_) + 1, 0) LW_SB LW_MFMA(g_, 1) LW_MFMA(g_, 7) LW_SB LW_LOAD1((g_) + 1, 1) LW_SB  \
+        LW_MFMA(g_, 2) LW_MFMA(g_, 8) LW_SB LW_LOAD1((g_) + 1, 2) LW_SB LW_MFMA(g_, 3) LW_MFMA(g_, 9) LW_SB LW_LOAD1((g_) + 1, 3) LW_SB  \
+        LW_MFMA(g_, 4) LW_MFMA(g_, 10) LW_SB LW_LOAD1((g_) + 1, 4) LW_SB LW_MFMA(g_, 5) LW_MFMA(g_, 11) LW_SB LW_LOAD1((g_) + 1, 5) LW_SB
+        LW_SB LW_LOAD1(0, 0) LW_LOAD1(0, 1) LW_LOAD1(0, 2) LW_LOAD1(0, 3) LW_LOAD1(0, 4) LW_LOAD1(0, 5)
+        LW_GROUP(0) LW_GROUP(1) LW_GROUP(2) LW_GROUP(3) LW_GROUP(4) LW_GROUP(5) LW_GROUP(6) LW_GROUP(7)
+#undef LW_GROUP
+#undef LW_MFMA
+#undef LW_SB
+#undef LW_LOAD1
+#undef LW_TRR
         hr_barrier();                                        // the producers' next tile has landed; this one is consumed
         cur = cur == 2 ? 0 : cur + 1;
     }
@@ -619,8 +753,13 @@ int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float*
     const int tiles = N * cdiv(W, LT_W) * cdiv(H, LT_H);
     const int grid = tiles < 256 * 8 ? tiles : 256 * 8;
     const float neg = mask_mode == MASK_LEAKY ? vsr_slope(slope) : 0.f;
-    hipLaunchKernelGGL(last2_dgrad_kernel, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg,
-                       (bf16_t*)dst, N, H, W, mask_mode);
+    if ((long long)3 * H * W * 4 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;                     // in-tile source offsets are 32-bit
+    if (sign_bits)
+        hipLaunchKernelGGL(last2_dgrad_kernel<2>, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode);
+    else if (aux)
+        hipLaunchKernelGGL(last2_dgrad_kernel<1>, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode);
+    else
+        hipLaunchKernelGGL(last2_dgrad_kernel<0>, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
