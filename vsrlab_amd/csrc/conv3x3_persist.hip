@@ -636,6 +636,14 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                                 ow[jj] = pk_max_i16(pk_bf16(v[2 * jj], v[2 * jj + 1]), 0u);
                                 if (!ABL(1)) sout[k] |= pk_min_u16(ow[jj], k11) << (4 * nb + jj);
                             }
+                        } else if (ACT == ACT_LEAKY && !HAS_RES && MASK == MASK_NONE && !ABL(1)) {
+                            // conv_last.0: LeakyReLU = max(v, slope v) (0 < slope < 1), sign bits from the packed words as in the ReLU case
+                            // (bit = "the stored half is positive", what sign_bits_c64_kernel computes from a stored activation)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                ow[jj] = pk_bf16(fmaxf(v[2 * jj], v[2 * jj] * slope), fmaxf(v[2 * jj + 1], v[2 * jj + 1] * slope));
+                                sout[k] |= pk_min_u16(pk_max_i16(ow[jj], 0u), k11) << (4 * nb + jj);
+                            }
                         } else if (ACT == ACT_NONE && !HAS_RES && MASK == MASK_RELU_BITS) {
                             // dgrad(conv2) * ReLU': multiply the packed halves by their 0 / 1 bits
 #pragma unroll
