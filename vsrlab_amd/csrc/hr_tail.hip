@@ -310,6 +310,24 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
     int tn = walk.first / (ntx * nty), tyi, txi;               // image, tile row, tile column of the walk, advanced by adds and carries
     { const int r0 = walk.first - tn * (ntx * nty); tyi = r0 / ntx; txi = r0 - tyi * ntx; }
     const int sn = walk.stride / (ntx * nty), sty = (walk.stride - sn * (ntx * nty)) / ntx, stx = walk.stride - sn * (ntx * nty) - sty * ntx;
+    // fast path: the 12 LR values of a tile are requested one tile AHEAD (at the end of the previous iteration, behind its stores) and
+    // combined after the tile's K loop: with the K loop down to ~1.2 k cycles their L2 round trip was the longest thing in a tile
+    float lvn[3][4], lyn = 0.f, lxn = 0.f;
+    bool okn = false;
+    auto prefetch = [&](int n, int ty0, int tx0) {
+        okn = ty0 + oyr < a.H && tx0 + oxr < a.W;
+        int y0 = (ty0 >> 2) + yk, x0 = (tx0 >> 2) + xk;
+        lyn = lyc; lxn = lxc;
+        if (y0 < 0) { y0 = 0; lyn = 0.f; }
+        if (x0 < 0) { x0 = 0; lxn = 0.f; }
+        if (!okn) { y0 = 0; x0 = 0; }                        // lanes of an outside pixel load the frame's first pixel and store nothing
+        const int y1 = y0 + (y0 < a.base_h - 1 ? 1 : 0), x1 = x0 + (x0 < a.base_w - 1 ? 1 : 0);
+        const float* bp = a.base_lr + (long long)n * a.base_nstride;
+        const int o00 = y0 * a.base_w + x0, o01 = y0 * a.base_w + x1, o10 = y1 * a.base_w + x0, o11 = y1 * a.base_w + x1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lvn[c][0] = bp[c * lr_plane + o00]; lvn[c][1] = bp[c * lr_plane + o01]; lvn[c][2] = bp[c * lr_plane + o10]; lvn[c][3] = bp[c * lr_plane + o11]; }
+    };
+    if (fast && walk.first < walk.end) prefetch(tn, tyi * LT_H, txi * LT_W);
     __syncthreads();                                         // the first tile is in LDS
     int cur = 0;
     for (int t = walk.first; t < walk.end; t += walk.stride) {
@@ -323,21 +341,13 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
         const int oy = ty0 + oyr, ox = tx0 + oxr;
         const bool ok = oy < a.H && ox < a.W;
         float add[4] = {0.f, 0.f, 0.f, 0.f};
+        float lv[3][4], ly = 0.f, lx = 0.f;
         if (fast) {
-            int y0 = (ty0 >> 2) + yk, x0 = (tx0 >> 2) + xk;
-            float ly = lyc, lx = lxc;
-            if (y0 < 0) { y0 = 0; ly = 0.f; }
-            if (x0 < 0) { x0 = 0; lx = 0.f; }
-            if (!ok) { y0 = 0; x0 = 0; }                     // lanes of an outside pixel load the frame's first pixel and store nothing
-            const int y1 = y0 + (y0 < a.base_h - 1 ? 1 : 0), x1 = x0 + (x0 < a.base_w - 1 ? 1 : 0);
-            const float* bp = a.base_lr + (long long)n * a.base_nstride;
-            const int o00 = y0 * a.base_w + x0, o01 = y0 * a.base_w + x1, o10 = y1 * a.base_w + x0, o11 = y1 * a.base_w + x1;
-            float lv[3][4];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { lv[c][0] = bp[c * lr_plane + o00]; lv[c][1] = bp[c * lr_plane + o01]; lv[c][2] = bp[c * lr_plane + o10]; lv[c][3] = bp[c * lr_plane + o11]; }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                add[c] = bs[c] + ((1.f - ly) * ((1.f - lx) * lv[c][0] + lx * lv[c][1]) + ly * ((1.f - lx) * lv[c][2] + lx * lv[c][3]));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lv[c][k] = lvn[c][k];
+            ly = lyn; lx = lxn;
         } else if (ok) {
             int y0 = 0, y1 = 0, x0 = 0, x1 = 0; float ly = 0.f, lx = 0.f;
             if (a.base_lr) { hr_bil4(oy, a.base_h, y0, y1, ly); hr_bil4(ox, a.base_w, x0, x1, lx); }
@@ -384,6 +394,11 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
 #undef CP_SB
 #undef CP_LOAD1
 #undef CP_DSR
+        if (fast) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                add[c] = bs[c] + ((1.f - ly) * ((1.f - lx) * lv[c][0] + lx * lv[c][1]) + ly * ((1.f - lx) * lv[c][2] + lx * lv[c][3]));
+        }
         float* dst = reinterpret_cast<float*>(a.dst[0]) + (long long)n * a.dst_nstride + (long long)oy * a.Wd + ox;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -393,6 +408,7 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
             const float v = (q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : s3) + add[c];
             if (ok) dst[c * plane] = v;
         }
+        if (fast && t + walk.stride < walk.end) prefetch(tn, tyi * LT_H, txi * LT_W);    // (tn, tyi, txi) already name the next tile
         __syncthreads();                                     // the producers' next tile has landed; this one is consumed
         cur ^= 1;
     }
