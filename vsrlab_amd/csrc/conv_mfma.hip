@@ -23,6 +23,8 @@
 
 namespace {
 
+__device__ uint4 g_cm_zero[4];  // 64 zero bytes: the source of every out-of-image chunk
+
 constexpr int TW = 32;          // tile width  (MFMA N)
 constexpr int RW = 2;           // rows per wave
 constexpr int TH = 4 * RW;      // tile height
@@ -166,32 +168,58 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                 // planar fp32, 3 real channels -> 16-channel padded pixels
                 const float* base = reinterpret_cast<const float*>(a.src[s]) + (long long)n * a.src_nstride[s];
                 const long long plane = (long long)a.Hs * a.Ws;
-                for (int p = tid; p < NPIX; p += NTHREADS) {
-                    const int ty = p / TWH, tx = p - ty * TWH;
-                    const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
-                    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-                    if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = (long long)(vy * a.in_step + a.src_oy[s]) * a.Ws + (vx * a.in_step + a.src_ox[s]);
-                        const int pc = a.planar_c ? a.planar_c : 3;
-                        c0 = base[o]; c1 = pc > 1 ? base[o + plane] : 0.f; c2 = pc > 2 ? base[o + 2 * plane] : 0.f;
+                const float* zf = reinterpret_cast<const float*>(g_cm_zero);
+                const int pc = a.planar_c ? a.planar_c : 3;
+                for (int p0 = tid; p0 < NPIX; p0 += 2 * NTHREADS) {        // two pixels per thread and round: six unconditional loads in flight
+                    float cv[2][3];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int p = p0 + k * NTHREADS < NPIX ? p0 + k * NTHREADS : 0;
+                        const int ty = p / TWH, tx = p - ty * TWH;
+                        const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
+                        const bool in = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+                        const float* sp = in ? base + (long long)(vy * a.in_step + a.src_oy[s]) * a.Ws + (vx * a.in_step + a.src_ox[s]) : zf;
+                        cv[k][0] = sp[0]; cv[k][1] = *(in && pc > 1 ? sp + plane : zf); cv[k][2] = *(in && pc > 2 ? sp + 2 * plane : zf);
                     }
-                    *reinterpret_cast<chunk_t*>(lds_in + (p * 2 + swz<2>(p, 0)) * CHB) = make_chunk3(c0, c1, c2, (T*)nullptr);
-                    *reinterpret_cast<chunk_t*>(lds_in + (p * 2 + swz<2>(p, 1)) * CHB) = zero_chunk<T>();
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int p = p0 + k * NTHREADS;
+                        if (p < NPIX) {
+                            *reinterpret_cast<chunk_t*>(lds_in + (p * 2 + swz<2>(p, 0)) * CHB) = make_chunk3(cv[k][0], cv[k][1], cv[k][2], (T*)nullptr);
+                            *reinterpret_cast<chunk_t*>(lds_in + (p * 2 + swz<2>(p, 1)) * CHB) = zero_chunk<T>();
+                        }
+                    }
                 }
             } else {
+                // batches of 4 chunks per thread: every load of a batch is requested (out-of-image chunks from a zero word: a
+                // conditional load compiles to a branch and a vmcnt(0) per element, i.e. one memory round trip after the other --
+                // r03 ISA of the trunk-stem instantiation) before the first one is written to LDS
                 const T* base = reinterpret_cast<const T*>(a.src[s]) + (long long)n * a.src_nstride[s];
-                for (int idx = tid; idx < NPIX * CP; idx += NTHREADS) {
-                    const int p = idx / CP, c = idx - p * CP;
-                    const int ty = p / TWH, tx = p - ty * TWH;
-                    const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
-                    chunk_t v = zero_chunk<T>();
-                    if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = pm_off(vy * a.in_step + a.src_oy[s], vx * a.in_step + a.src_ox[s], c, a.Ws, C);
-                        v = *reinterpret_cast<const chunk_t*>(base + o);
+                const T* zsrc = reinterpret_cast<const T*>(g_cm_zero);
+                constexpr int SB = 4;
+                for (int idx0 = tid; idx0 < NPIX * CP; idx0 += SB * NTHREADS) {
+                    chunk_t v[SB];
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) {
+                        const int idx = idx0 + k * NTHREADS;
+                        const int ic = idx < NPIX * CP ? idx : 0;
+                        const int p = ic / CP, c = ic - p * CP;
+                        const int ty = p / TWH, tx = p - ty * TWH;
+                        const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
+                        const bool in = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+                        const T* sp = in ? base + pm_off(vy * a.in_step + a.src_oy[s], vx * a.in_step + a.src_ox[s], c, a.Ws, C) : zsrc;
+                        v[k] = *reinterpret_cast<const chunk_t*>(sp);
                     }
-                    int sc;
-                    if (CP == 8) sc = swz<8>(p, c); else if (CP == 4) sc = swz<4>(p, c); else sc = swz<2>(p, c);
-                    *reinterpret_cast<chunk_t*>(lds_in + (p * CP + sc) * CHB) = v;
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) {
+                        const int idx = idx0 + k * NTHREADS;
+                        if (idx < NPIX * CP) {
+                            const int p = idx / CP, c = idx - p * CP;
+                            int sc;
+                            if (CP == 8) sc = swz<8>(p, c); else if (CP == 4) sc = swz<4>(p, c); else sc = swz<2>(p, c);
+                            *reinterpret_cast<chunk_t*>(lds_in + (p * CP + sc) * CHB) = v[k];
+                        }
+                    }
                 }
             }
         }
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < MAXPT; ++i) {
                         const int idx = tid + i * NTHREADS;
-                        if (idx < SLAB_CHUNKS) wreg[tt][i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)tt * SLAB_CHUNKS + idx) * 8);
+                        wreg[tt][i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)tt * SLAB_CHUNKS + (idx < SLAB_CHUNKS ? idx : 0)) * 8);
                     }
                 for (int st = 0; st < NST; ++st) {
                     if (st > 0) __syncthreads();                      // every wave has finished reading the previous row's slabs
@@ -237,8 +265,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                             for (int i = 0; i < MAXPT; ++i) {
                                 const int idx = tid + i * NTHREADS;
-                                if (idx < SLAB_CHUNKS)
-                                    wreg[tt][i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)((st + 1) * TPS + tt) * SLAB_CHUNKS + idx) * 8);
+                                wreg[tt][i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)((st + 1) * TPS + tt) * SLAB_CHUNKS + (idx < SLAB_CHUNKS ? idx : 0)) * 8);
                             }
                     }
 #pragma unroll
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < MAXPT; ++i) {
                 const int idx = tid + i * NTHREADS;
-                if (idx < SLAB_CHUNKS) wreg[i] = *reinterpret_cast<const chunk_t*>(ws + (long long)idx * 8);
+                wreg[i] = *reinterpret_cast<const chunk_t*>(ws + (long long)(idx < SLAB_CHUNKS ? idx : 0) * 8);     // unconditional: a guarded load is a branch + vmcnt(0) per element
             }
 #pragma unroll
             for (int i = 0; i < MAXPT; ++i) {
@@ -298,9 +325,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < MAXPT; ++i) {
                         const int idx = tid + i * NTHREADS;
-                        if (idx < SLAB_CHUNKS)
-                            wreg[i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)(tap + 1) * SLAB_CHUNKS + idx) * 8);
+                        wreg[i] = *reinterpret_cast<const chunk_t*>(ws + ((long long)(tap + 1) * SLAB_CHUNKS + (idx < SLAB_CHUNKS ? idx : 0)) * 8);
                     }
+                    __builtin_amdgcn_sched_barrier(0);         // the requests stay HERE, in front of the tap's MFMAs (hipcc sinks them to their use behind the MFMAs otherwise)
                 }
 #pragma unroll
                 for (int ks = 0; ks < C / 16; ++ks) {

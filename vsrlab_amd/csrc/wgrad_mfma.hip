@@ -61,6 +61,8 @@ __device__ __forceinline__ s16x4_t tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
+__device__ uint4 g_wg_zero[4];      // 64 zero bytes: the source of every out-of-image chunk of the generic kernel's staging loops
+
 // KS: kernel size; CX/COUT: LDS channel counts of X / dY (multiples of 16); *PLANAR: operand is a
 // planar fp32 3-channel image (LR frames, SR cotangent) padded to 16 channels on the way into LDS.
 template <typename T, int KS, int CX, bool XPLANAR, int COUT, bool DYPLANAR>
@@ -111,61 +113,95 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
             if (XPLANAR) {
                 const float* base = reinterpret_cast<const float*>(a.x[seg]) + (long long)n * a.x_nstride;
                 const long long plane = (long long)a.Hx * a.Wx;
-                for (int p = tid; p < NPIXX; p += NTHREADS) {
-                    const int ty = p / TWH, tx = p - ty * TWH;
-                    const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
-                    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-                    if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = (long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox);
-                        c0 = base[o]; c1 = base[o + plane]; c2 = base[o + 2 * plane];
+                const float* zf = reinterpret_cast<const float*>(g_wg_zero);
+                for (int p0 = tid; p0 < NPIXX; p0 += 2 * NTHREADS) {      // two pixels per thread and round, six unconditional loads in flight
+                    float cv[2][3];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int p = p0 + k * NTHREADS < NPIXX ? p0 + k * NTHREADS : 0;
+                        const int ty = p / TWH, tx = p - ty * TWH;
+                        const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
+                        const bool in = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+                        const float* sp = in ? base + (long long)(vy * a.x_step + a.x_oy) * a.Wx + (vx * a.x_step + a.x_ox) : zf;
+                        const long long pl = in ? plane : 0;
+                        cv[k][0] = sp[0]; cv[k][1] = sp[pl]; cv[k][2] = sp[2 * pl];
                     }
-                    *reinterpret_cast<chunk_t*>(lx + (p * 2 + 0) * CHB) = wchunk3(c0, c1, c2, (T*)nullptr);
-                    *reinterpret_cast<chunk_t*>(lx + (p * 2 + 1) * CHB) = wzero<T>();
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int p = p0 + k * NTHREADS;
+                        if (p < NPIXX) {
+                            *reinterpret_cast<chunk_t*>(lx + (p * 2 + 0) * CHB) = wchunk3(cv[k][0], cv[k][1], cv[k][2], (T*)nullptr);
+                            *reinterpret_cast<chunk_t*>(lx + (p * 2 + 1) * CHB) = wzero<T>();
+                        }
+                    }
                 }
             } else {
+                // batches of 4 chunks per thread, every load requested before the first LDS write; out-of-image chunks come from a zero
+                // word (a guarded load compiles to a branch + vmcnt(0) per element: one memory round trip after the other, r03)
                 const T* base = reinterpret_cast<const T*>(a.x[seg]) + (long long)n * a.x_nstride;
-                for (int idx = tid; idx < NPIXX * CPX; idx += NTHREADS) {
-                    const int p = idx / CPX, c = idx - p * CPX;
-                    const int ty = p / TWH, tx = p - ty * TWH;
-                    const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
-                    chunk_t v = wzero<T>();
-                    if (vy >= 0 && vy < a.H && vx >= 0 && vx < a.W) {
-                        const long long o = pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c + a.x_coff, a.Wx, a.x_ctotal ? a.x_ctotal : CX);
-                        v = *reinterpret_cast<const chunk_t*>(base + o);
+                const T* zsrc = reinterpret_cast<const T*>(g_wg_zero);
+                for (int idx0 = tid; idx0 < NPIXX * CPX; idx0 += 4 * NTHREADS) {
+                    chunk_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = idx0 + k * NTHREADS, ic = idx < NPIXX * CPX ? idx : 0;
+                        const int p = ic / CPX, c = ic - p * CPX;
+                        const int ty = p / TWH, tx = p - ty * TWH;
+                        const int vy = ty0 + ty - PAD, vx = tx0 + tx - PAD;
+                        const bool in = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+                        const T* sp = in ? base + pm_off(vy * a.x_step + a.x_oy, vx * a.x_step + a.x_ox, c + a.x_coff, a.Wx, a.x_ctotal ? a.x_ctotal : CX) : zsrc;
+                        v[k] = *reinterpret_cast<const chunk_t*>(sp);
                     }
-                    *reinterpret_cast<chunk_t*>(lx + (p * CPX + wswz<CPX>(p, c)) * CHB) = v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = idx0 + k * NTHREADS;
+                        if (idx < NPIXX * CPX) {
+                            const int p = idx / CPX, c = idx - p * CPX;
+                            *reinterpret_cast<chunk_t*>(lx + (p * CPX + wswz<CPX>(p, c)) * CHB) = v[k];
+                        }
+                    }
                 }
             }
             // ---- stage dY (no halo) + bias partial sums ----
             if (DYPLANAR) {
                 const float* base = reinterpret_cast<const float*>(a.dy[seg]) + (long long)n * a.dy_nstride;
                 const long long plane = (long long)a.Hy * a.Wy;
+                const float* zf = reinterpret_cast<const float*>(g_wg_zero);
                 for (int p = tid; p < NPIXY; p += NTHREADS) {
                     const int ty = p / TW, tx = p - ty * TW;
                     const int vy = ty0 + ty, vx = tx0 + tx;
-                    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-                    if (vy < a.H && vx < a.W) {
-                        const long long o = (long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox);
-                        const int pc = a.dy_planar_c ? a.dy_planar_c : 3;
-                        c0 = base[o]; c1 = pc > 1 ? base[o + plane] : 0.f; c2 = pc > 2 ? base[o + 2 * plane] : 0.f;
-                    }
+                    const int pc = a.dy_planar_c ? a.dy_planar_c : 3;
+                    const bool in = vy < a.H && vx < a.W;
+                    const float* sp = in ? base + (long long)(vy * a.dy_step + a.dy_oy) * a.Wy + (vx * a.dy_step + a.dy_ox) : zf;
+                    const float c0 = sp[0], c1 = *(in && pc > 1 ? sp + plane : zf), c2 = *(in && pc > 2 ? sp + 2 * plane : zf);   // unconditional loads
                     bsum[0] += c0; bsum[1] += c1; bsum[2] += c2;
                     *reinterpret_cast<chunk_t*>(ly + (p * 2 + 0) * CHB) = wchunk3(c0, c1, c2, (T*)nullptr);
                     *reinterpret_cast<chunk_t*>(ly + (p * 2 + 1) * CHB) = wzero<T>();
                 }
             } else {
                 const T* base = reinterpret_cast<const T*>(a.dy[seg]) + (long long)n * a.dy_nstride;
-                for (int idx = tid; idx < NPIXY * CPY; idx += NTHREADS) {   // NTHREADS % CPY == 0: chunk id is fixed per thread
-                    const int p = idx / CPY, c = idx - p * CPY;
-                    const int ty = p / TW, tx = p - ty * TW;
-                    const int vy = ty0 + ty, vx = tx0 + tx;
-                    chunk_t v = wzero<T>();
-                    if (vy < a.H && vx < a.W) {
-                        const long long o = pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c + a.dy_coff, a.Wy, a.dy_ctotal ? a.dy_ctotal : COUT);
-                        v = *reinterpret_cast<const chunk_t*>(base + o);
+                const T* zsrc = reinterpret_cast<const T*>(g_wg_zero);
+                for (int idx0 = tid; idx0 < NPIXY * CPY; idx0 += 4 * NTHREADS) {   // NTHREADS % CPY == 0: chunk id is fixed per thread
+                    chunk_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = idx0 + k * NTHREADS, ic = idx < NPIXY * CPY ? idx : 0;
+                        const int p = ic / CPY, c = ic - p * CPY;
+                        const int ty = p / TW, tx = p - ty * TW;
+                        const int vy = ty0 + ty, vx = tx0 + tx;
+                        const bool in = idx < NPIXY * CPY && vy < a.H && vx < a.W;
+                        const T* sp = in ? base + pm_off(vy * a.dy_step + a.dy_oy, vx * a.dy_step + a.dy_ox, c + a.dy_coff, a.Wy, a.dy_ctotal ? a.dy_ctotal : COUT) : zsrc;
+                        v[k] = *reinterpret_cast<const chunk_t*>(sp);
                     }
-                    chunk_sum(v, bsum);
-                    *reinterpret_cast<chunk_t*>(ly + (p * CPY + wswz<CPY>(p, c)) * CHB) = v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = idx0 + k * NTHREADS;
+                        if (idx < NPIXY * CPY) {
+                            const int p = idx / CPY, c = idx - p * CPY;
+                            chunk_sum(v[k], bsum);
+                            *reinterpret_cast<chunk_t*>(ly + (p * CPY + wswz<CPY>(p, c)) * CHB) = v[k];
+                        }
+                    }
                 }
             }
             __syncthreads();
