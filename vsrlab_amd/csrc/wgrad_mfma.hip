@@ -315,6 +315,14 @@ __global__ void wgrad_reduce_kernel(const float* slab, int nwg, int slab_stride,
     float s = 0.f;
     if (p) {
         int w = grp;
+        for (; w + 44 < nwg; w += 48) {                      // 12 slabs per thread in flight (4 were one memory round trip per 4 slabs: 16 us per launch); the same sums in the same order
+            float v[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = p[(long long)(w + 4 * k) * slab_stride];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            s += (v[4] + v[5]) + (v[6] + v[7]);
+            s += (v[8] + v[9]) + (v[10] + v[11]);
+        }
         for (; w + 12 < nwg; w += 16) {
             const float v0 = p[(long long)w * slab_stride], v1 = p[(long long)(w + 4) * slab_stride];
             const float v2 = p[(long long)(w + 8) * slab_stride], v3 = p[(long long)(w + 12) * slab_stride];
