@@ -483,6 +483,7 @@ int launch_inst(const ConvArgs& a, hipStream_t st) {
 
 int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st);
 int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);      // hr_tail.hip
+int vsr_launch_planar_c64_conv(const ConvArgs& a, hipStream_t st);    // hr_tail.hip
 int vsr_launch_conv7x7_persist(const ConvArgs& a, int cin, int cop, int epi, int num_cus, hipStream_t st);   // conv7x7_persist.hip
 
 // VSRLAB_AMD_GENERIC_CONV=1 routes the hot shape through the generic tiled kernel (A/B testing only; common.h: vsr_env()).
@@ -505,6 +506,11 @@ int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar
     if (dtype == VSR_BF16 && ks == 3 && nsrc == 1 && ca == 64 && cb == 64 && !last_planar && cout_t == 32 && epi == EPI_PLANAR &&
         !vsr_force_generic_conv()) {
         const int ps = vsr_launch_c64_to_planar(a, st);
+        if (ps != VSR_ERR_UNSUPPORTED) return ps;
+    }
+    // planar fp32 (1 or 3 channels) -> 64 channels: the streaming kernel of hr_tail.hip (one K = 27 MFMA per 16 x 16 block)
+    if (dtype == VSR_BF16 && ks == 3 && nsrc == 1 && last_planar && ca == 16 && cb == 16 && cout_t == 64 && epi == EPI_NHWC && !vsr_force_generic_conv()) {
+        const int ps = vsr_launch_planar_c64_conv(a, st);
         if (ps != VSR_ERR_UNSUPPORTED) return ps;
     }
     // SPyNet's 7x7 layers: persistent kernels with streamed / resident weights (conv7x7_persist.hip)

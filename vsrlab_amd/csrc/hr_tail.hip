@@ -33,11 +33,15 @@ __device__ __forceinline__ void hr_barrier() {
 // of the bf16 activation (the whole 1.06 GB C0 at HR).
 // MODE: where the activation-gradient mask comes from -- 0 none, 1 the bf16 activation `aux`, 2 its sign bits (compile-time: with run-time
 // branches on the two pointers hipcc put a vmcnt(0) at the top of every tile, i.e. waited for the previous tile's output stores)
-template <int MODE>
+// PACKED: the same kernel as the generic planar (1 or 3 channels, fp32) -> 64-channel 3x3 convolution of the engines (discriminator conv_0
+// and conv_9's data gradient, the pre-clean stack's stem and its out conv's data gradient): weights in pack_weights_kernel's layout
+// [tap][64 rows][16] (the packer already flipped / transposed them for a data gradient), + bias, + LeakyReLU(slope), `pc` input planes.
+template <int MODE, bool PACKED>
 __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restrict__ dsr, long long dsr_nstride,
                                                             const float* __restrict__ w, const bf16_t* __restrict__ aux,
                                                             const uint2* __restrict__ sign_bits, float neg,
-                                                            bf16_t* __restrict__ dst, int N, int H, int W, int mask_mode) {
+                                                            bf16_t* __restrict__ dst, int N, int H, int W, int mask_mode,
+                                                            const bf16_t* __restrict__ wpack, const float* __restrict__ bias, float act_slope, int pc) {
     __shared__ float tile[2][3 * LT_PL];
     const int tid = threadIdx.x, lane = tid & 63, w4 = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -58,10 +62,17 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int ci = pm_acc_chan(mb, l15);             // A rows are indexed by the lane column itself; paired-block channel order
-            fa[mb][j] = (bf16_t)(k < 27 ? w[((long long)c * 64 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.f);
+            if (PACKED) fa[mb][j] = k < 27 ? wpack[(tap * 64 + ci) * 16 + c] : (bf16_t)0.f;
+            else fa[mb][j] = (bf16_t)(k < 27 ? w[((long long)c * 64 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.f);
         }
     }
     (void)mask_mode;
+    // PACKED epilogue: bias of this lane's 16 output channels (piece k: channels 8 (4 k + q) + j) and the LeakyReLU slope (1 = none)
+    float bsv[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsv[k][j] = (PACKED && bias) ? bias[8 * (4 * k + q) + j] : 0.f;
 
     // haloed dSR tile -> LDS (zeros outside the image) by LDS-DMA, 4 bytes per lane (the 34-float rows of a plane start 3 floats before
     // a 16-byte boundary), one whole tile ahead into the other buffer: 16 instructions of 64 floats per tile, 4 per wave.  r03: the
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
             const int e = (w4 + 4 * i) * 64 + lane;
             const int c = e / LT_PL, rem = e - c * LT_PL, yy = rem / LT_RS, xx = rem - yy * LT_RS;
             const int vy = ty0 + yy - 1, vx = tx0 + xx - 1;
-            const char* sp = (vy >= 0 && vy < H && vx >= 0 && vx < W) ? org + srel[i] : zsrc;
+            const char* sp = (vy >= 0 && vy < H && vx >= 0 && vx < W && (!PACKED || c < pc)) ? org + srel[i] : zsrc;
             if (e < 3 * LT_PL)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                                  (__attribute__((address_space(3))) void*)(&tile[b][(w4 + 4 * i) * 64]), 4, 0, 0);
@@ -167,6 +178,10 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = acc[2 * k][nb][j]; v[4 + j] = acc[2 * k + 1][nb][j]; }
+                if (PACKED) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float t = v[j] + bsv[k][j]; v[j] = fmaxf(t, t * act_slope); }       // slope 1: no activation
+                }
                 if (MODE == 2) {
                     const unsigned wbits = k ? sb.y : sb.x;
 #pragma unroll
@@ -771,11 +786,37 @@ int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float*
     const float neg = mask_mode == MASK_LEAKY ? vsr_slope(slope) : 0.f;
     if ((long long)3 * H * W * 4 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;                     // in-tile source offsets are 32-bit
     if (sign_bits)
-        hipLaunchKernelGGL(last2_dgrad_kernel<2>, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode);
+        hipLaunchKernelGGL((last2_dgrad_kernel<2, false>), dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode, (const bf16_t*)nullptr, (const float*)nullptr, 1.f, 3);
     else if (aux)
-        hipLaunchKernelGGL(last2_dgrad_kernel<1>, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode);
+        hipLaunchKernelGGL((last2_dgrad_kernel<1, false>), dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode, (const bf16_t*)nullptr, (const float*)nullptr, 1.f, 3);
     else
-        hipLaunchKernelGGL(last2_dgrad_kernel<0>, dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode);
+        hipLaunchKernelGGL((last2_dgrad_kernel<0, false>), dim3(grid), dim3(LT_NT), 0, st, dsr, dsr_nstride, w, (const bf16_t*)aux, (const uint2*)sign_bits, neg, (bf16_t*)dst, N, H, W, mask_mode, (const bf16_t*)nullptr, (const float*)nullptr, 1.f, 3);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}
+
+// bf16 conv3x3 from a planar fp32 source of 1 or 3 channels to 64 pixel-major channels with PACKED weights ([9][64][16], as every engine
+// packs them for the generic kernel's (3, 1, 16, 16, planar, 64) shape): + bias, LeakyReLU, activation-gradient mask from `aux`.
+// VSR_ERR_UNSUPPORTED: the caller uses the generic kernel.
+int vsr_launch_planar_c64_conv(const ConvArgs& a, hipStream_t st) {
+    if (a.nz != 1 || a.in_step != 1 || a.src_oy[0] || a.src_ox[0] || a.Hs != a.H || a.Ws != a.W || a.out_step != 1 || a.out_oy[0] || a.out_ox[0] ||
+        a.Hd != a.H || a.Wd != a.W || !a.src[0] || !a.dst[0] || a.res[0] || a.CD != 64 || a.cout_real != 64 || a.sign_out[0] ||
+        (a.act != ACT_NONE && a.act != ACT_LEAKY) || (a.aux[0] && a.mask_mode != MASK_RELU && a.mask_mode != MASK_LEAKY) ||
+        a.dst_nstride != pm_image_elems(a.H, a.W, 64))
+        return VSR_ERR_UNSUPPORTED;
+    const int pc = a.planar_c ? a.planar_c : 3;
+    if (pc < 1 || pc > 3 || (long long)3 * a.H * a.W * 4 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;
+    const int tiles = a.N * cdiv(a.W, LT_W) * cdiv(a.H, LT_H);
+    const int grid = tiles < 256 * 8 ? tiles : 256 * 8;
+    const float slope = a.act == ACT_LEAKY ? vsr_slope(a.leaky_slope) : 1.f;
+    const float neg = (a.aux[0] && a.mask_mode == MASK_LEAKY) ? vsr_slope(a.leaky_slope) : 0.f;
+    const float* src = reinterpret_cast<const float*>(a.src[0]);
+    if (a.aux[0])
+        hipLaunchKernelGGL((last2_dgrad_kernel<1, true>), dim3(grid), dim3(LT_NT), 0, st, src, a.src_nstride[0], (const float*)nullptr, (const bf16_t*)a.aux[0], (const uint2*)nullptr, neg,
+                           (bf16_t*)a.dst[0], a.N, a.H, a.W, a.mask_mode, (const bf16_t*)a.wpack, a.bias, slope, pc);
+    else
+        hipLaunchKernelGGL((last2_dgrad_kernel<0, true>), dim3(grid), dim3(LT_NT), 0, st, src, a.src_nstride[0], (const float*)nullptr, (const bf16_t*)nullptr, (const uint2*)nullptr, neg,
+                           (bf16_t*)a.dst[0], a.N, a.H, a.W, a.mask_mode, (const bf16_t*)a.wpack, a.bias, slope, pc);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
