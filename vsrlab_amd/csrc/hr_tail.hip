@@ -447,7 +447,7 @@ __device__ __forceinline__ s16x4_t hr_tr_read(const char* p) {
 
 __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dy,
                                                                long long dy_nstride, float* __restrict__ slab, int slab_stride,
-                                                               int N, int H, int W) {
+                                                               int N, int H, int W, int pc) {
     extern __shared__ __attribute__((aligned(16))) char tiles[];      // 2 x LW_TILE; reused for the final reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_kernel(const bf16_t* __r
         for (int rr = 0; rr < 2; ++rr) {
             const int oy = ty0 + 2 * w4 + rr, ox = tx0 + 8 * q;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (i15 < 3 && oy < H) {
+            if (i15 < pc && oy < H) {
                 const float* dp = dy + (long long)n * dy_nstride + i15 * plane + (long long)oy * W + ox;
                 if (ox + 8 <= W && ((reinterpret_cast<size_t>(dp) & 15) == 0)) {
                     const float4 a0 = *reinterpret_cast<const float4*>(dp), a1 = *reinterpret_cast<const float4*>(dp + 4);
@@ -573,9 +573,9 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_kernel(const bf16_t* __r
                     float v = acc[tap][mb][j];
 #pragma unroll
                     for (int ww = 0; ww < 3; ++ww) v += xch[((ww * 36 + tap * 4 + mb) * 4 + j) * 64 + lane];
-                    if (co < 3) sl[((long long)tap * 32 + co) * 64 + mb * 16 + 4 * q + j] = v;      // C[m = ci 4q+j][n = co]
+                    if (co < pc) sl[((long long)tap * 32 + co) * 64 + mb * 16 + 4 * q + j] = v;     // C[m = ci 4q+j][n = co]
                 }
-        if (lane < 3) {                                      // db[co]: lanes (co, q = 0..3) of the 4 waves
+        if (lane < pc) {                                     // db[co]: lanes (co, q = 0..3) of the 4 waves
             float b = 0.f;
             for (int ww = 0; ww < 4; ++ww)
                 for (int qq = 0; qq < 4; ++qq) b += bx[ww * 64 + qq * 16 + lane];
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_kernel(const bf16_t* __r
 
 __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dy,
                                                                long long dy_nstride, float* __restrict__ slab, int slab_stride,
-                                                               int N, int H, int W) {
+                                                               int N, int H, int W, int pc) {
     extern __shared__ __attribute__((aligned(16))) char tiles[];      // ring: 3 x LW_TILE + 3 x LW_DY; reused for the final reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t
             const int ty0 = tyi * LT_H, tx0 = txi * LT_W;
             const int row = lane >> 3, xc = (lane & 7) * 4;
             const float* sp = dy + (long long)n * dy_nstride + (long long)(w4 - 1) * plane + (long long)(ty0 + row) * W + tx0 + xc;
-            const char* spc = (ty0 + row < H && tx0 + xc < W) ? reinterpret_cast<const char*>(sp) : zsrc;
+            const char* spc = (w4 - 1 < pc && ty0 + row < H && tx0 + xc < W) ? reinterpret_cast<const char*>(sp) : zsrc;     // planes >= pc do not exist: zeros
             FP_GLDS16(spc, tiles + 3 * LW_TILE + buf * LW_DY + (w4 - 1) * 1024);
         };
         struct { int T, n, ty, tx; } it;
@@ -696,13 +696,13 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t
         // B[k = pixel 8 q + j][n = co i15] of this wave's two rows, from the dY tile the producers staged (zeros for co >= 3)
         bf16x8_t fb[2];
         {
-            const float* dt = reinterpret_cast<const float*>(tiles + 3 * LW_TILE + cur * LW_DY) + (i15 < 3 ? i15 : 0) * 256 + 8 * q;
+            const float* dt = reinterpret_cast<const float*>(tiles + 3 * LW_TILE + cur * LW_DY) + (i15 < pc ? i15 : 0) * 256 + 8 * q;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const float4 a0 = *reinterpret_cast<const float4*>(dt + (2 * w4 + rr) * 32), a1 = *reinterpret_cast<const float4*>(dt + (2 * w4 + rr) * 32 + 4);
                 const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float vv = i15 < 3 ? v[j] : 0.f; fb[rr][j] = (bf16_t)vv; bsum += vv; }
+                for (int j = 0; j < 8; ++j) { const float vv = i15 < pc ? v[j] : 0.f; fb[rr][j] = (bf16_t)vv; bsum += vv; }
             }
         }
         // K loop in 8 groups g = (X row R = g >> 1 of the wave's 4 haloed rows, ci-block pair mp = g & 1): the group's 6 A fragments (ci
@@ -763,9 +763,9 @@ __global__ __launch_bounds__(FP_NT, 1) void last2_wgrad_ring_kernel(const bf16_t
                     float v = acc[tap][mb][j];
 #pragma unroll
                     for (int ww = 0; ww < 3; ++ww) v += xch[((ww * 36 + tap * 4 + mb) * 4 + j) * 64 + lane];
-                    if (co < 3) sl[((long long)tap * 32 + co) * 64 + mb * 16 + 4 * q + j] = v;      // C[m = ci 4q+j][n = co]
+                    if (co < pc) sl[((long long)tap * 32 + co) * 64 + mb * 16 + 4 * q + j] = v;     // C[m = ci 4q+j][n = co]
                 }
-        if (lane < 3) {                                      // db[co]: lanes (co, q = 0..3) of the 4 waves
+        if (lane < pc) {                                     // db[co]: lanes (co, q = 0..3) of the 4 waves
             float b = 0.f;
             for (int ww = 0; ww < 4; ++ww)
                 for (int qq = 0; qq < 4; ++qq) b += bx[ww * 64 + qq * 16 + lane];
@@ -841,8 +841,8 @@ int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st) {
 // Partial slabs of the weight gradient of a 64 -> 3 conv3x3 with a planar fp32 cotangent (bf16 X, pixel-major 64 channels);
 // *nslabs = slabs written, in the layout of vsr_wgrad_slab_dims(3, 64, 16).
 int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride, float* slab, int slab_stride, int N, int H, int W,
-                           int* nslabs, hipStream_t st) {
-    if (!x || !dy || !slab || !nslabs || N < 1 || H < 1 || W < 1) return VSR_ERR_BADARG;
+                           int* nslabs, hipStream_t st, int pc) {
+    if (!x || !dy || !slab || !nslabs || N < 1 || H < 1 || W < 1 || pc < 1 || pc > 3) return VSR_ERR_BADARG;
     if (pm_image_elems(LT_H + 4, W, 64) * 2 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;
     constexpr int LDS = (3 * 144 * 64 + 4 * 64) * 4 > 2 * LW_TILE ? (3 * 144 * 64 + 4 * 64) * 4 : 2 * LW_TILE;     // 111,616 B
     static VsrDevOnce once;
@@ -855,11 +855,11 @@ int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride,
         constexpr int LDSR = 3 * LW_TILE + 3 * LW_DY;                                                // 147,456 B
         static VsrDevOnce once_r;
         { const int rc = vsr_set_max_dynamic_lds(once_r, reinterpret_cast<const void*>(last2_wgrad_ring_kernel), LDSR); if (rc != VSR_OK) return rc; }
-        hipLaunchKernelGGL(last2_wgrad_ring_kernel, dim3(grid), dim3(FP_NT), LDSR, st, (const bf16_t*)x, dy, dy_nstride, slab, slab_stride, N, H, W);
+        hipLaunchKernelGGL(last2_wgrad_ring_kernel, dim3(grid), dim3(FP_NT), LDSR, st, (const bf16_t*)x, dy, dy_nstride, slab, slab_stride, N, H, W, pc);
         HIP_CHECK_RET(hipGetLastError());
         return VSR_OK;
     }
-    hipLaunchKernelGGL(last2_wgrad_kernel, dim3(grid), dim3(FP_NT), LDS, st, (const bf16_t*)x, dy, dy_nstride, slab, slab_stride, N, H, W);
+    hipLaunchKernelGGL(last2_wgrad_kernel, dim3(grid), dim3(FP_NT), LDS, st, (const bf16_t*)x, dy, dy_nstride, slab, slab_stride, N, H, W, pc);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

@@ -39,7 +39,7 @@ int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu
 int vsr_launch_add_f32(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);
 int vsr_launch_last2_wgrad(const void* x, const float* dy, long long dy_nstride, float* slab, int slab_stride, int N, int H, int W,
-                           int* nslabs, hipStream_t st);
+                           int* nslabs, hipStream_t st, int pc = 3);      // pc: planes of the planar cotangent (1..3)
 int vsr_launch_last2_dgrad(const float* dsr, long long dsr_nstride, const float* w, const void* aux, void* dst, int N, int H, int W,
                            int mask_mode, hipStream_t st, const void* sign_bits = nullptr, float slope = 0.f);
 // One weight pack of vsr_launch_pack_weights as data: a forward packs ~465 tensors, batched into a handful of launches

@@ -769,6 +769,16 @@ int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_p
             return launch_wgrad_pc(a, nwg / 2, st);
         }
     }
+    // 64 -> (1..3) channels with a planar fp32 cotangent (conv_last.2, the pre-clean out conv, the discriminator's conv_9): the streaming
+    // kernel of hr_tail.hip, one slab per CU
+    if (!vsr_env().generic_wgrad && dtype == VSR_BF16 && ks == 3 && cx == 64 && !x_planar && cout == 16 && dy_planar && a.nseg == 1 && a.x_step == 1 &&
+        a.dy_step == 1 && !a.x_oy && !a.x_ox && !a.dy_oy && !a.dy_ox && a.Hx == a.H && a.Wx == a.W && a.Hy == a.H && a.Wy == a.W && !a.x_ctotal && !a.x_coff &&
+        a.x_nstride == pm_image_elems(a.H, a.W, 64)) {
+        const int rc = vsr_launch_last2_wgrad(a.x[0], reinterpret_cast<const float*>(a.dy[0]), a.dy_nstride, a.slab, a.slab_stride, a.N, a.H, a.W, nslabs, st,
+                                              a.dy_planar_c ? a.dy_planar_c : 3);
+        if (rc != VSR_ERR_UNSUPPORTED) return rc;
+        *nslabs = nwg;
+    }
     // SPyNet's 7x7 layers (train_flow): producer / consumer kernel, all seven kernel rows in one launch (wgrad7x7_pc.hip); the
     // caller's nwg is also what its slab buffer holds of this shape's partials
     if (!vsr_env().generic_wgrad && dtype == VSR_BF16 && ks == 7 && !x_planar && !dy_planar) {
