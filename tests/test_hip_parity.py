@@ -946,6 +946,41 @@ def test_diet_arena_matches_the_full_arena(dtype):
             assert rel_l2(out["diet"][1][k], v) < 1e-5, (shape, k, rel_l2(out["diet"][1][k], v))
 
 
+def _chain_timeouts():
+    import ctypes
+    from vsrlab_amd import _lib
+    out = ctypes.c_uint(0)
+    lib = _lib.load()
+    assert lib.vsr_debug_chain_timeouts(ctypes.byref(out)) == 0
+    return out.value
+
+
+def test_trunk_chain_launch_is_bit_identical_to_one_launch_per_layer():
+    """conv3x3_chain.hip: the 2 rb convolutions of a frame's residual blocks (and their 2 rb - 1 data gradients) as ONE launch whose
+    workgroups hand tiles to each other through row counters (write-through stores, agent-scope counters), against
+    VSRLAB_AMD_CHAIN=0 = one launch per layer: the same tile arithmetic on the same operands, so sr and EVERY gradient must
+    be bit-identical -- one stale tile anywhere in 2 x t x (4 rb - 1) layers would show.  Sizes: fewer tiles than
+    workgroups (every workgroup's next item depends on its current one: the publish-at-once path), ragged edges, a batch
+    of two, and a size with several tiles per workgroup and row (deferred publishes, look-ahead polls); run twice
+    (L1 / L2 warm with the previous run's lines).  No dependency wait may have timed out."""
+    dev = _gpu()
+    t0 = _chain_timeouts()
+    for (shape, blocks) in [((1, 3, 3, 20, 40), 3), ((2, 3, 3, 45, 100), 4), ((1, 2, 3, 200, 330), 6), ((1, 2, 3, 270, 480), 30)]:
+        out = {}
+        for mode in ("0", "1", "1b"):
+            os.environ["VSRLAB_AMD_CHAIN"] = mode[0]
+            try:
+                _, _, _, sr, grads = _run_basicvsr("bf16", 64, blocks, shape, 93, 94, dev)
+            finally:
+                os.environ.pop("VSRLAB_AMD_CHAIN", None)
+            out[mode] = (sr, grads)
+        for mode in ("1", "1b"):
+            assert torch.equal(out["0"][0], out[mode][0]), (shape, mode, "sr")
+            for k, v in out["0"][1].items():
+                assert torch.equal(out[mode][1][k], v), (shape, mode, k, rel_l2(out[mode][1][k], v))
+    assert _chain_timeouts() == t0
+
+
 def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
     is process-wide, so they run in a child, like the pipelined-conv A/B above."""

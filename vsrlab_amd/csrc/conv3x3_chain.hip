@@ -1,0 +1,513 @@
+// A whole chain of dependent 3x3 64 -> 64 convolutions in ONE launch: the 60 layers of a frame's 30 ResidualConv blocks
+// (core/modules/conv.py:85-92 inside conv.py:94-103; basicvsr.py:56-58,71-73) forward, and their 59 data gradients backward.
+//
+// Why: a 540p layer is 2040 tiles of 8x32 pixels = 8 per CU.  As its own launch (conv3x3_persist.hip) a layer pays ~6.4 k
+// cycles of prologue (kernel arguments, 72 KiB of weights, the first tile's HBM round trip) and ~6 us of launch / drain around 8 x
+// 6.1 k cycles of tiles: a quarter of the 38-45 us a layer takes.  Here the workgroups stay resident over all layers of the
+// chain; a layer boundary costs a workgroup one weight reload, and nobody waits for the slowest workgroup of a layer.
+//
+// How the layers are ordered without a grid barrier:
+//   * work items = (layer, tile) in layer-major, row-major order, handed out by ONE global atomic counter.  An item depends only
+//     on items with smaller indices (the 3x3 halo: tile rows r-1, r, r+1 of the previous layer), and an item is only ever taken
+//     by a RUNNING workgroup, which works through its items in order: the smallest unfinished item can always proceed, whatever
+//     share of the grid is resident (the engine's second stream may hold CUs; two chains may run side by side).
+//   * a finished tile is PUBLISHED per MFMA wave: outputs are stored write-through (global_store ... sc1: the per-XCD L2s are not
+//     coherent), the wave waits for its stores (s_waitcnt vmcnt(0)), then one lane adds 1 to the counter of (layer, tile row):
+//     a row is complete at 4 waves x tiles-per-row.  MI355X_MICROARCH "inter-workgroup visibility", the row "each storing wave
+//     for itself / sc1 poll / workgroup barrier between the poll and every load".  The add is DEFERRED to the top of the wave's
+//     next epilogue, where the stores have long been acknowledged -- unless the workgroup's next item is not known to be ready
+//     (then the wave drains and publishes at once: on small images the next item can depend on this one).
+//   * consumers: the leader producer wave polls the three row counters of an item two tiles ahead (relaxed agent-scope loads)
+//     and leaves the verdict in LDS; a workgroup barrier later the producer waves issue the tile's LDS-DMA (sc1: bypasses the
+//     CU's L1).  Not ready at that point -> every producer wave polls for itself (bounded by a 1 s clock; a timeout raises a
+//     global error word that ends every wait, so the grid always drains, and the host refuses the result).  The residual operand
+//     of a layer is the output of the layer before the previous one at the same tile: complete by transitivity, loaded sc1.
+//   * every buffer of a chain is written exactly once and read only after its row counters say so (training arena: one buffer
+//     per layer), so no CU can hold a stale line of it.
+//
+// The tile loop itself (K loop, fragment schedule, epilogues) is conv3x3_persist.hip's; see there for the LDS images.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int PTW = 32, PTH = 8, PNT = 512;
+constexpr int PTWH = PTW + 2, PTHH = PTH + 2, PNPIX = PTHH * PTWH;
+constexpr int W_BYTES = 9 * 64 * 64 * 2;
+constexpr int IN_BYTES = PNPIX * 128;
+constexpr int BIAS_OFF = W_BYTES + 2 * IN_BYTES;
+constexpr int CTL_OFF = BIAS_OFF + 256;                                   // 3 item slots of 8 ints
+constexpr int P_LDS = CTL_OFF + 128;                                      // 161,152 <= 163,840
+constexpr int IN_CHUNKS = PNPIX * 8;
+constexpr int NPIECE_T = (IN_CHUNKS + 63) / 64;
+constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11; the leader wave (w4 = 0) always issues exactly 11
+
+__device__ uint4 g_chain_zero_chunk[2];
+__device__ unsigned g_chain_timeouts;           // waits given up since the module was loaded (never reset: vsr_debug_chain_timeouts)
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    bf16x2_t p = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) { unsigned r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+#define GLDS16_SC1(src, dst)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 16)
+#define GP(T, x) ((__attribute__((address_space(1))) T*)(x))
+
+// rows r-1, r, r+1 of one image's row counters (cnt points at row 0) have reached `target`; lanes 0..2 look at one row each
+__device__ __forceinline__ bool rows_ready(const gu32* cnt, int ty, int nty, unsigned target, int lane) {
+    bool ok = true;
+    const int r = ty - 1 + lane;
+    if (lane < 3 && r >= 0 && r < nty) ok = __hip_atomic_load(cnt + r, RLX_AGENT) >= target;
+    return __all(ok);
+}
+// the slow path of a consumer: poll until ready; false = gave up (the error word is set: results are void)
+__device__ __forceinline__ bool rows_wait(const gu32* cnt, int ty, int nty, unsigned target, int lane, gu32* err) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (rows_ready(cnt, ty, nty, target, lane)) return true;
+        if (__hip_atomic_load(err, RLX_AGENT) != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {                // 1 s of the 100 MHz clock
+            if (lane == 0) { __hip_atomic_fetch_add(err, 1u, RLX_AGENT); __hip_atomic_fetch_add(GP(unsigned, &g_chain_timeouts), 1u, RLX_AGENT); }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+// EVEN: the variant of the chain's layers that are not CHAIN_SKIP (forward chains: CHAIN_RELU, backward chains: CHAIN_MASK)
+template <int EVEN>
+__global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2);            // 0: MFMA + epilogue, 1: LDS-DMA producer
+    const int w4 = __builtin_amdgcn_readfirstlane(wave & 3);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int pxl = (l15 >= 4 && l15 < 12) ? 2 * (l15 - 4) : (l15 < 4 ? 2 * l15 + 1 : 2 * (l15 - 8) + 1);
+    char* lds_w = smem;
+    char* lds_t = smem + W_BYTES;
+    int* const ctl = reinterpret_cast<int*>(smem + CTL_OFF);              // slot s: ctl + 8 s = {item, layer, n, ty, tx, ready, -, -}
+
+    const int H = ka.H, W = ka.W;
+    const int ntx = cdiv(W, PTW), nty = cdiv(H, PTH);
+    const int per = ntx * nty, tiles = ka.N * per, rows = ka.N * nty;
+    const int total = tiles * ka.nlayers;
+    const int WS = pm_ws(W);
+    const long long img = pm_image_elems(H, W, 64);
+    char* const base = ka.base;
+    gu32* const work = GP(unsigned, ka.sync);
+    gu32* const err = work + 1;
+    gu32* const cnt0 = work + 16;                                          // [layer][rows]
+    const unsigned target = 4u * (unsigned)ntx;
+
+    // ---- the first two items of this workgroup ----
+    if (tid == 256) {
+        const int v = (int)__hip_atomic_fetch_add(work, 2u, RLX_AGENT);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int it = v + s;
+            int* sl = ctl + 8 * s;
+            if (it < total) {
+                const int l = it / tiles, r = it - l * tiles, n = r / per, r2 = r - n * per, ty = r2 / ntx;
+                sl[0] = it; sl[1] = l; sl[2] = n; sl[3] = ty; sl[4] = r2 - ty * ntx; sl[5] = l == 0 ? 1 : 0;
+            } else {
+                sl[0] = -1; sl[1] = 0; sl[2] = 0; sl[3] = 0; sl[4] = 0; sl[5] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (ctl[0] < 0) return;                                                // more workgroups than items (uniform)
+
+#define W_LOAD(wv, wg)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
+        const int idx = tid + i * 256;                                                                                   \
+        const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
+        wv[i] = (wg)[(tap * 64 + pm_acc_chan(r >> 4, r & 15)) * 8 + c];                                                  \
+    }
+#define W_STORE(wv)                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
+        const int idx = tid + i * 256;                                                                                   \
+        const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
+        *reinterpret_cast<u32x4_t*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wv[i];                     \
+    }
+    constexpr int WCH = 9 * 64 * 8 / 256;
+
+    if (role == 1) {
+        // =================== producer waves ===================
+        const bool leader = w4 == 0;
+        const auto* zsrc = GP(const char, g_chain_zero_chunk);
+        int rel[NPIECE_W];
+#pragma unroll
+        for (int i = 0; i < NPIECE_W; ++i) {
+            const int idx = (w4 + 4 * i) * 64 + lane;
+            const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
+            const int c = rem / PTWH, tx = rem - c * PTWH;
+            const int dx = tx - 1;
+            rel[i] = ((((ty - 1) * WS + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
+        }
+        int p_layer = -1;
+        const char* p_src = nullptr;
+        auto issue = [&](int layer, int n, int tyi, int txi, int buf) {
+            if (layer != p_layer) { p_layer = layer; p_src = base + (unsigned long long)ka.layer[layer].src * 256ull; }
+            const int ty0 = tyi * PTH, tx0 = txi * PTW;
+            const auto* org = GP(const char, p_src) + ((long long)n * img + pm_off(ty0, tx0, 0, W, 64)) * 2;
+            char* dstb = lds_t + buf * IN_BYTES;
+            if (ty0 >= 1 && ty0 + PTH < H && tx0 >= 1 && tx0 + PTW < W) {
+#pragma unroll
+                for (int i = 0; i < NPIECE_W; ++i) {
+                    const int piece = w4 + 4 * i;
+                    if (piece < NPIECE_T && piece * 64 + lane < IN_CHUNKS) GLDS16_SC1(org + rel[i], dstb + piece * 1024);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPIECE_W; ++i) {
+                    const int piece = w4 + 4 * i;
+                    const int idx = piece * 64 + lane;
+                    const int ty = idx / (8 * PTWH), rem = idx - ty * (8 * PTWH);
+                    const int tx = rem % PTWH;
+                    const int vy = ty0 + ty - 1, vx = tx0 + tx - 1;
+                    const auto* s = (vy >= 0 && vy < H && vx >= 0 && vx < W) ? org + rel[i] : zsrc;
+                    if (piece < NPIECE_T && idx < IN_CHUNKS) GLDS16_SC1(s, dstb + piece * 1024);
+                }
+            }
+        };
+        // item 0: nothing was polled for it yet
+        {
+            const int l0 = ctl[1], n0 = ctl[2], ty0 = ctl[3], tx0 = ctl[4];
+            if (l0 > 0) (void)rows_wait(cnt0 + (long long)(l0 - 1) * rows + (long long)n0 * nty, ty0, nty, target, lane, err);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            issue(l0, n0, ty0, tx0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // weights of the first layer and the first tile are in LDS
+        int cur_layer = ctl[1];
+        for (int k = 0;; ++k) {
+            const int* sc = ctl + 8 * (k % 3);
+            if (sc[0] < 0) break;
+            const int layer_k = __builtin_amdgcn_readfirstlane(sc[1]);
+            int* s1 = ctl + 8 * ((k + 1) % 3);
+            const int it1 = __builtin_amdgcn_readfirstlane(s1[0]);
+            // the leader asks for item k+2 first: the atomic's round trip runs under the poll / DMA issue below
+            unsigned nx = 0xffffffffu;                                    // (never a counter value)
+            if (leader && it1 >= 0 && lane == 0)
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(nx) : "v"(work), "v"(1u) : "memory");
+            if (it1 >= 0) {
+                const int l1 = __builtin_amdgcn_readfirstlane(s1[1]), n1 = __builtin_amdgcn_readfirstlane(s1[2]);
+                const int ty1 = __builtin_amdgcn_readfirstlane(s1[3]), tx1 = __builtin_amdgcn_readfirstlane(s1[4]);
+                if (__builtin_amdgcn_readfirstlane(s1[5]) == 0) {
+                    (void)rows_wait(cnt0 + (long long)(l1 - 1) * rows + (long long)n1 * nty, ty1, nty, target, lane, err);
+                    if (leader && lane == 0) s1[5] = 1;   // tells the MFMA waves that their deferred publish cannot be what we wait for
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                issue(l1, n1, ty1, tx1, (k + 1) & 1);
+            }
+            if (leader) {
+                int* s2 = ctl + 8 * ((k + 2) % 3);
+                int it2 = -1, l2 = 0, n2 = 0, ty2 = 0, tx2 = 0;
+                bool ok2 = false;
+                if (it1 >= 0) {
+                    // exactly NPIECE_W vector-memory instructions of this wave are younger than the atomic (vmcnt counts in issue order)
+                    asm volatile("s_waitcnt vmcnt(11)" : "+v"(nx) :: "memory");
+                    static_assert(NPIECE_W == 11, "the counted wait above");
+                    if (__builtin_amdgcn_readfirstlane((int)nx) == -1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx) :: "memory");   // (belt and braces)
+                    it2 = __builtin_amdgcn_readfirstlane((int)nx);
+                    if (it2 >= total) it2 = -1;
+                    else {
+                        l2 = it2 / tiles; const int r = it2 - l2 * tiles; n2 = r / per; const int r2 = r - n2 * per; ty2 = r2 / ntx; tx2 = r2 - ty2 * ntx;
+                        // its dependencies, looked at now, used a barrier later (the result returns behind this wave's DMA pieces,
+                        // i.e. under the wait for the tile that is needed anyway)
+                        ok2 = l2 == 0 || rows_ready(cnt0 + (long long)(l2 - 1) * rows + (long long)n2 * nty, ty2, nty, target, lane);
+                    }
+                }
+                if (lane == 0) { s2[0] = it2; s2[1] = l2; s2[2] = n2; s2[3] = ty2; s2[4] = tx2; s2[5] = ok2 ? 1 : 0; }
+            }
+            if (layer_k != cur_layer) { cur_layer = layer_k; __syncthreads(); }     // the MFMA waves' weight reload
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // =================== MFMA waves ===================
+        u32x4_t wv[WCH];
+        {
+            const auto* wg = GP(const u32x4_t, base + (unsigned long long)ka.layer[ctl[1]].w * 256ull);
+            W_LOAD(wv, wg)
+        }
+        unsigned a_lo[2], a_hi[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            a_lo[kk] = (unsigned)((l15 * 8 + ((4 * kk + q) ^ ((l15 >> 1) & 7))) * 16);
+            a_hi[kk] = a_lo[kk] + 6 * 8192;
+        }
+        const int b_lane = w4 * 2 * (PTWH * 128) + q * (PTWH * 16) + pxl * 16;
+        unsigned loff[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int dx = (nb & 1) * 16 + pxl;
+            loff[nb] = (((((w4 * 2 + (nb >> 1))) * WS + (dx >> 5)) * 8 + q) * 256 + (dx & 31) * 8) * 2;     // BYTES from the tile's origin
+        }
+        W_STORE(wv)
+        if (tid < 64) {
+            const unsigned bo = ka.layer[ctl[1]].bias;
+            reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = bo != 0xffffffffu ? GP(const float, base + (unsigned long long)bo * 256ull)[pm_acc_chan(tid >> 4, tid & 15)] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4_t bvec[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) bvec[mb] = *reinterpret_cast<const f32x4_t*>(smem + BIAS_OFF + (mb * 16 + 4 * q) * 4);
+        bf16x8_t idA[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) idA[hb][j] = (bf16_t)((q == (l15 >> 2) && j == 4 * hb + (l15 & 3)) ? 1.f : 0.f);
+
+        // the layer whose operands are loaded
+        int cur_layer = __builtin_amdgcn_readfirstlane(ctl[1]);
+        unsigned long long p_dst, p_res, p_sbits, p_sout;
+        int variant;
+        auto layer_ptrs = [&](int l) {
+            const ChainLayer L = ka.layer[l];
+            p_dst = (unsigned long long)base + (unsigned long long)L.dst * 256ull;
+            p_res = (unsigned long long)base + (unsigned long long)L.res * 256ull;
+            p_sbits = (unsigned long long)base + (unsigned long long)L.sbits * 256ull;
+            p_sout = L.sout != 0xffffffffu ? (unsigned long long)base + (unsigned long long)L.sout * 256ull : 0ull;
+            variant = L.variant;
+        };
+        layer_ptrs(cur_layer);
+
+        bool pending = false;                 // a finished tile of this wave whose row counter has not been told yet
+        gu32* pend_cnt = nullptr;
+        int cur = 0;
+        // item k of this workgroup (slot k % 3); the next slot is read at the top of a tile and used at its end
+        int item = __builtin_amdgcn_readfirstlane(ctl[0]), layer = cur_layer, tn = __builtin_amdgcn_readfirstlane(ctl[2]);
+        int tyi = __builtin_amdgcn_readfirstlane(ctl[3]), txi = __builtin_amdgcn_readfirstlane(ctl[4]);
+        for (int k = 0; item >= 0; ++k) {
+            const int* sn = ctl + 8 * ((k + 1) % 3);     // the next item: read behind the K loop (registers), used at the end of the tile
+            int nx_item = -1, nx_layer = 0, nx_n = 0, nx_ty = 0, nx_tx = 0, nx_ok = 0;
+            if (layer != cur_layer) {
+                // every MFMA wave is past the previous tile's K loop (the barrier at its end): the weight image is free
+                cur_layer = layer;
+                layer_ptrs(layer);
+                const auto* wg = GP(const u32x4_t, base + (unsigned long long)ka.layer[layer].w * 256ull);
+                W_LOAD(wv, wg)
+                float bv = 0.f;
+                const unsigned bo = ka.layer[layer].bias;
+                if (tid < 64 && bo != 0xffffffffu) bv = GP(const float, base + (unsigned long long)bo * 256ull)[pm_acc_chan(tid >> 4, tid & 15)];
+                W_STORE(wv)
+                if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = bv;
+                __syncthreads();
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) bvec[mb] = *reinterpret_cast<const f32x4_t*>(smem + BIAS_OFF + (mb * 16 + 4 * q) * 4);
+            }
+            const int tile = item - layer * tiles;
+            const int ty0 = tyi * PTH, tx0 = txi * PTW;
+            const long long tbase = (long long)tn * img + pm_off(ty0, tx0, 0, W, 64);
+            const bool full = ty0 + PTH <= H && tx0 + PTW <= W;
+            bool ok[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) ok[nb] = (tx0 + (nb & 1) * 16 + pxl < W) && (ty0 + w4 * 2 + (nb >> 1) < H);
+            gu32* const my_cnt = cnt0 + (long long)layer * rows + (long long)tn * nty + tyi;
+
+            auto body = [&](auto VC) {
+                constexpr int V = decltype(VC)::value;
+                constexpr bool HAS_RES = V == CHAIN_SKIP, BITS = V == CHAIN_MASK;
+                u32x4_t rr[2][4];
+                u32x2_t sbits = {0u, 0u};
+                if (BITS) sbits = GP(const u32x2_t, p_sbits)[(long long)tile * 256 + w4 * 64 + lane];
+                if (HAS_RES) {
+                    // the residual = the output of layer - 2 of this chain (or the chain's input): write-through stored there, sc1 here
+                    const unsigned long long rbase = p_res + (unsigned long long)tbase * 2ull;
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const unsigned lo = loff[nb];
+                        // (inline asm is not padded by hipcc: `s_nop 4` = the wait states between the scalar adds that made rbase and a
+                        // vector-memory instruction using it as its base; cdna_hip_programming.md 5.7 item 2)
+                        if (full) {
+                            if (nb == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
+                            else asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
+                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 sc1" : "=v"(rr[1][nb]) : "v"(lo), "s"(rbase) : "memory");
+                        } else {
+                            rr[0][nb] = u32x4_t{0u, 0u, 0u, 0u}; rr[1][nb] = u32x4_t{0u, 0u, 0u, 0u};
+                            if (ok[nb]) {
+                                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "+v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
+                                asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 sc1" : "+v"(rr[1][nb]) : "v"(lo), "s"(rbase) : "memory");
+                            }
+                        }
+                    }
+                }
+                f32x4_t acc[4][4];
+                bf16x8_t fa[2][4], fb[2][4];
+                const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);
+#define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define CV_LOADA(tap_, kk_, slot, mb) DSR(fa[slot][mb], (tap_ < 6 ? a_lo[kk_] : a_hi[kk_]), (tap_ < 6 ? tap_ : tap_ - 6) * 8192 + (mb) * 2048);
+#define CV_LOADB(ky_, kx_, kk_, slot, nb) DSR(fb[slot][nb], bb, (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
+#define CV_LOAD(s, slot)                                                                                               \
+                {                                                                                                      \
+                    constexpr int tap_ = (s) / 2, kk_ = (s) % 2, ky_ = tap_ / 3, kx_ = tap_ % 3;                       \
+                    CV_LOADA(tap_, kk_, slot, 0) CV_LOADA(tap_, kk_, slot, 1) CV_LOADA(tap_, kk_, slot, 2) CV_LOADA(tap_, kk_, slot, 3) \
+                    CV_LOADB(ky_, kx_, kk_, slot, 0) CV_LOADB(ky_, kx_, kk_, slot, 1) CV_LOADB(ky_, kx_, kk_, slot, 2) CV_LOADB(ky_, kx_, kk_, slot, 3) \
+                }
+#define CV_MFMA(s, mb, nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(s) % 2][mb], fb[(s) % 2][nb], (s) == 0 ? bvec[mb] : acc[mb][nb], 0, 0, 0);
+#define CV_ML_A(s, mb, nb, lmb)                                                                                        \
+                CV_MFMA(s, mb, nb)                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+                if ((s) + 1 < 18) { constexpr int t1_ = ((s) + 1) / 2, k1_ = ((s) + 1) % 2; CV_LOADA(t1_, k1_, ((s) + 1) % 2, lmb) } \
+                __builtin_amdgcn_sched_barrier(0);
+#define CV_ML_B(s, mb, nb, lnb)                                                                                        \
+                CV_MFMA(s, mb, nb)                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+                if ((s) + 1 < 18) { constexpr int t1_ = ((s) + 1) / 2, k1_ = ((s) + 1) % 2; CV_LOADB(t1_ / 3, t1_ % 3, k1_, ((s) + 1) % 2, lnb) } \
+                __builtin_amdgcn_sched_barrier(0);
+#define CV_STEP(s)                                                                                                     \
+                {                                                                                                      \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                    CV_ML_A(s, 0, 0, 0) CV_ML_A(s, 0, 1, 1) CV_ML_A(s, 0, 2, 2) CV_ML_A(s, 0, 3, 3)                    \
+                    CV_ML_B(s, 1, 0, 0) CV_ML_B(s, 1, 1, 1) CV_ML_B(s, 1, 2, 2) CV_ML_B(s, 1, 3, 3)                    \
+                    CV_MFMA(s, 2, 0) CV_MFMA(s, 2, 1) CV_MFMA(s, 2, 2) CV_MFMA(s, 2, 3)                                \
+                    CV_MFMA(s, 3, 0) CV_MFMA(s, 3, 1) CV_MFMA(s, 3, 2) CV_MFMA(s, 3, 3)                                \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                CV_LOAD(0, 0)
+                CV_STEP(0) CV_STEP(1) CV_STEP(2) CV_STEP(3) CV_STEP(4) CV_STEP(5) CV_STEP(6) CV_STEP(7) CV_STEP(8)
+                CV_STEP(9) CV_STEP(10) CV_STEP(11) CV_STEP(12) CV_STEP(13) CV_STEP(14) CV_STEP(15) CV_STEP(16) CV_STEP(17)
+#undef CV_ML_A
+#undef CV_ML_B
+#undef CV_STEP
+#undef CV_MFMA
+#undef CV_LOAD
+#undef CV_LOADB
+#undef CV_LOADA
+#undef DSR
+                nx_item = sn[0]; nx_layer = sn[1]; nx_n = sn[2]; nx_ty = sn[3]; nx_tx = sn[4]; nx_ok = sn[5];
+                // ---- epilogue ----
+                // vmcnt(0): this tile's operands are here, and the PREVIOUS tile's stores (issued a K loop ago) are acknowledged:
+                // now its row counter may be told (R1: every storing wave drains, then adds for itself)
+                // (the builtin, so that hipcc's scoreboard knows the queue is empty: behind an asm wait it would wait again, for the
+                // publishing atomic below, in front of the first use of the sign bits)
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0) alone
+                __builtin_amdgcn_sched_barrier(0);
+                if (pending) {
+                    if (lane == 0) __hip_atomic_fetch_add(pend_cnt, 1u, RLX_AGENT);
+                    pending = false;
+                }
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(idA[mb & 1], __builtin_bit_cast(bf16x8_t, rr[mb >> 1][nb]), acc[mb][nb], 0, 0, 0);
+                }
+                unsigned sout[2] = {0u, 0u};
+                const unsigned k11 = 0x00010001u;
+                const unsigned long long dbase = p_dst + (unsigned long long)tbase * 2ull;
+                auto epilogue = [&](auto FULL) {
+                    const unsigned long long db = dbase;          // (asm operands do not capture by themselves in a generic lambda)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        if (decltype(FULL)::value || ok[nb]) {
+                            const unsigned lo = loff[nb];
+#pragma unroll
+                            for (int kq = 0; kq < 2; ++kq) {
+                                float v[8];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { v[j] = acc[2 * kq][nb][j]; v[4 + j] = acc[2 * kq + 1][nb][j]; }
+                                const unsigned wbits = kq ? sbits.y : sbits.x;
+                                unsigned ow[4];
+                                if (V == CHAIN_RELU) {
+#pragma unroll
+                                    for (int jj = 0; jj < 4; ++jj) {
+                                        ow[jj] = pk_max_i16(pk_bf16(v[2 * jj], v[2 * jj + 1]), 0u);
+                                        sout[kq] |= pk_min_u16(ow[jj], k11) << (4 * nb + jj);
+                                    }
+                                } else if (V == CHAIN_MASK) {
+#pragma unroll
+                                    for (int jj = 0; jj < 4; ++jj)
+                                        ow[jj] = pk_mul_lo_u16(pk_bf16(v[2 * jj], v[2 * jj + 1]), (wbits >> (4 * nb + jj)) & k11);
+                                } else {
+#pragma unroll
+                                    for (int jj = 0; jj < 4; ++jj) ow[jj] = pk_bf16(v[2 * jj], v[2 * jj + 1]);
+                                }
+                                const u32x4_t o = {ow[0], ow[1], ow[2], ow[3]};
+                                // write-through: the next layer's tiles may be loaded on another XCD
+                                // (asm: `s_nop 1` behind a 16-byte store, or hipcc's next instruction may overwrite the data registers before
+                                // the store has read them; `s_nop 4` in front of the first user of the freshly added base; 5.7 items 1, 2)
+                                if (kq == 0) {
+                                    if (nb == 0 || !decltype(FULL)::value) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
+                                    else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
+                                } else asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 sc1\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
+                            }
+                        }
+                    }
+                };
+                if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
+                if (V == CHAIN_RELU && p_sout) GP(u32x2_t, p_sout)[(long long)tile * 256 + w4 * 64 + lane] = u32x2_t{sout[0], sout[1]};
+            };
+            if (variant == CHAIN_SKIP) body(std::integral_constant<int, CHAIN_SKIP>{});
+            else body(std::integral_constant<int, EVEN>{});
+
+            pending = true; pend_cnt = my_cnt;
+            // The deferred publish is safe only if the workgroup's next tile does not wait for it: unless the producers have
+            // already seen that tile's dependencies complete, drain and publish now.
+            if (nx_item < 0 || nx_ok == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(pend_cnt, 1u, RLX_AGENT);
+                pending = false;
+            }
+            __syncthreads();                               // the next tile has landed; everybody has finished reading `cur`
+            cur ^= 1;
+            item = __builtin_amdgcn_readfirstlane(nx_item); layer = __builtin_amdgcn_readfirstlane(nx_layer); tn = __builtin_amdgcn_readfirstlane(nx_n);
+            tyi = __builtin_amdgcn_readfirstlane(nx_ty); txi = __builtin_amdgcn_readfirstlane(nx_tx);
+        }
+    }
+}
+
+}  // namespace
+
+// dependency waits that were given up (1 s each) since the library was loaded: anything but 0 voids the results of that run
+extern "C" int vsr_debug_chain_timeouts(unsigned* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_timeouts), sizeof(unsigned)) == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+size_t vsr_chain_sync_bytes(int nlayers, int N, int H) {
+    return ((size_t)(16 + (size_t)nlayers * N * cdiv(H, PTH)) * 4 + 255) & ~(size_t)255;
+}
+
+// a.sync: vsr_chain_sync_bytes() of device memory owned by this launch until it has finished (zeroed here, on the stream)
+int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st) {
+    if (!a.base || !a.sync || a.nlayers < 1 || a.nlayers > VSR_CHAIN_MAX_LAYERS || a.N < 1 || a.H < 1 || a.W < 1) return VSR_ERR_BADARG;
+    if (pm_image_elems(2 * PTH + 2, a.W, 64) * 2 > 0x7fffffffLL) return VSR_ERR_UNSUPPORTED;
+    const long long tiles = (long long)a.N * cdiv(a.W, PTW) * cdiv(a.H, PTH);
+    if (tiles * a.nlayers > 0x3fffffffLL) return VSR_ERR_UNSUPPORTED;
+    int even = -1;
+    for (int l = 0; l < a.nlayers; ++l) {
+        const ChainLayer& L = a.layer[l];
+        if (L.variant != CHAIN_RELU && L.variant != CHAIN_SKIP && L.variant != CHAIN_MASK) return VSR_ERR_BADARG;
+        if (L.variant != CHAIN_SKIP) { if (even >= 0 && even != L.variant) return VSR_ERR_UNSUPPORTED; even = L.variant; }
+        if (L.src == 0xffffffffu || L.dst == 0xffffffffu || L.w == 0xffffffffu) return VSR_ERR_BADARG;
+        if ((L.variant == CHAIN_SKIP && L.res == 0xffffffffu) || (L.variant == CHAIN_MASK && L.sbits == 0xffffffffu)) return VSR_ERR_BADARG;
+    }
+    auto kern = even == CHAIN_MASK ? conv3x3_c64_chain_kernel<CHAIN_MASK> : conv3x3_c64_chain_kernel<CHAIN_RELU>;
+    static VsrDevOnce once[2];
+    { const int rc = vsr_set_max_dynamic_lds(once[even == CHAIN_MASK], reinterpret_cast<const void*>(kern), P_LDS); if (rc != VSR_OK) return rc; }
+    HIP_CHECK_RET(hipMemsetAsync(a.sync, 0, vsr_chain_sync_bytes(a.nlayers, a.N, a.H), st));
+    int gx = num_cus / (a.cu_div > 1 ? a.cu_div : 1);
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = (int)tiles;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(PNT), P_LDS, st, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return VSR_OK;
+}

@@ -114,6 +114,7 @@ struct Plan {
     std::vector<size_t> dFeatB, dFF;            // per frame: d outputs[i], d feat_prop(i) from the reconstruction
     size_t S[2], dWp[2], slab[2];               // per direction / stream
     size_t far_cnt;                             // [2][t] ints: far-source counters of the gather-form warp backward
+    size_t chain_sync[2] = {0, 0};              // counters of the trunk chain launches (0: chains not planned)
     size_t G_C0, G_U1, G_U0, G_P;
     size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow / input gradient)
     size_t stem_wd_lr[2];       // data-gradient weights of the stems' 3 LR input channels (input gradient)
@@ -214,6 +215,8 @@ struct Plan {
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
         }
+        // the trunk chains' work / row counters (conv3x3_chain.hip), one block per direction (= per stream)
+        for (int dir = 0; dir < 2; ++dir) chain_sync[dir] = (bwd && !diet && dtype == VSR_BF16) ? b.take(vsr_chain_sync_bytes(VSR_CHAIN_MAX_LAYERS, n, h)) : 0;
         // appended last, so that every other offset is the same in modes 1 and 2
         dflows = 0;
         if (flowgrad && t > 1) {
@@ -444,6 +447,55 @@ int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm) {
     return VSR_OK;
 }
 
+// The 2 rb convolutions of a frame's residual blocks (and their data gradients) as ONE launch (conv3x3_chain.hip): training
+// arena only (every layer has a buffer of its own there), bf16.  VSRLAB_AMD_CHAIN=0 (read per call) = one launch per layer.
+bool chain_on(const Plan& p) {
+    if (!p.chain_sync[0] || !p.chain_sync[1] || 2 * p.rb > VSR_CHAIN_MAX_LAYERS) return false;
+    const char* e = getenv("VSRLAB_AMD_CHAIN");
+    return !(e && e[0] == '0');
+}
+unsigned chain_off(size_t o) { return (unsigned)(o >> 8); }
+int chain_launch(const ChainArgs& a, hipStream_t st) {
+    const char* e = getenv("VSRLAB_AMD_CHAIN");
+    if (e && e[0] == '2') {            // diagnostic: the same kernel, one layer per launch (no hand-off between workgroups)
+        for (int l = 0; l < a.nlayers; ++l) {
+            ChainArgs b = a;
+            b.nlayers = 1; b.layer[0] = a.layer[l];
+            CK(vsr_launch_conv3x3_chain(b, vsr_num_cus(), st));
+        }
+        return VSR_OK;
+    }
+    return vsr_launch_conv3x3_chain(a, vsr_num_cus(), st);
+}
+int trunk_chain_forward(const Ctx& c, const Plan& p, int dir, int i) {
+    ChainArgs a = {};
+    a.base = c.ws; a.sync = (unsigned*)c.at(p.chain_sync[dir]); a.N = p.n; a.H = p.h; a.W = p.w; a.nlayers = 2 * p.rb; a.cu_div = c.cu_div;
+    for (int b = 0; b < p.rb; ++b) {
+        ChainLayer& l1 = a.layer[2 * b];
+        l1 = {chain_off(p.xoff(dir, i, b)), chain_off(p.aoff(dir, i, b)), 0xffffffffu, 0xffffffffu, chain_off(p.sboff(dir, i, b)),
+              chain_off(p.blk_w[dir][2 * b]), chain_off(p.blk_b[dir][2 * b]), CHAIN_RELU};
+        ChainLayer& l2 = a.layer[2 * b + 1];
+        l2 = {chain_off(p.aoff(dir, i, b)), chain_off(p.xoff(dir, i, b + 1)), chain_off(p.xoff(dir, i, b)), 0xffffffffu, 0xffffffffu,
+              chain_off(p.blk_w[dir][2 * b + 1]), chain_off(p.blk_b[dir][2 * b + 1]), CHAIN_SKIP};
+    }
+    return chain_launch(a, c.st);
+}
+// dA_b = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b), dX_b = dX_{b+1} + dgrad(conv1)(dA_b) for b = rb-1 .. 1, and dA_0: 2 rb - 1 layers
+int trunk_chain_backward(const Ctx& c, const Plan& p, int dir, int i) {
+    ChainArgs a = {};
+    a.base = c.ws; a.sync = (unsigned*)c.at(p.chain_sync[dir]); a.N = p.n; a.H = p.h; a.W = p.w; a.cu_div = c.cu_div;
+    int L = 0;
+    for (int b = p.rb - 1; b >= 0; --b) {
+        a.layer[L++] = {chain_off(p.dxoff(dir, i, b + 1)), chain_off(p.g1off(dir, i, b)), 0xffffffffu, chain_off(p.sboff(dir, i, b)), 0xffffffffu,
+                        chain_off(p.blk_wd[dir][2 * b + 1]), 0xffffffffu, CHAIN_MASK};
+        if (b > 0)
+            a.layer[L++] = {chain_off(p.g1off(dir, i, b)), chain_off(p.dxoff(dir, i, b)), chain_off(p.dxoff(dir, i, b + 1)), 0xffffffffu, 0xffffffffu,
+                            chain_off(p.blk_wd[dir][2 * b]), 0xffffffffu, CHAIN_SKIP};
+    }
+    a.nlayers = L;
+    return chain_launch(a, c.st);
+}
+
 // one call of ResidualBlock (conv.py:94-103) on cat([lr_i, warped feat])
 int trunk_forward(const Ctx& c, const Plan& p, int dir, int i, const void* warped, const float* lrs) {
     const int n = p.n, h = p.h, w = p.w, rb = p.rb;
@@ -457,6 +509,7 @@ int trunk_forward(const Ctx& c, const Plan& p, int dir, int i, const void* warpe
         // the stem runs on the generic two-source kernel: its LeakyReLU sign bits for the block-0 data gradient come from a 66 MB pass
         if (p.bwd && c.dtype == VSR_BF16) CK(vsr_launch_sign_bits_c64(x, c.at(p.SBX0[dir][i]), n, h, w, c.st));
     }
+    if (chain_on(p)) return trunk_chain_forward(c, p, dir, i);
     for (int b = 0; b < rb; ++b) {      // x + conv2(relu(conv1(x)))   (conv.py:89-92)
         void* act = p.bwd ? c.at(p.aoff(dir, i, b)) : c.at(p.scratchA[dir]);
         void* xn = p.bwd ? c.at(p.xoff(dir, i, b + 1)) : x;   // inference: in place (residual read = own pixel)
@@ -755,10 +808,12 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
     } else {
         CK(vsr_launch_add_cast(c.dtype, dtop, nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
     }
-    for (int b = rb - 1; b >= 0; --b) {
+    const bool chain = chain_on(p);
+    if (chain) CK(trunk_chain_backward(c, p, dir, i));
+    for (int b = chain ? 0 : rb - 1; b >= 0; --b) {
         const void* dxn = c.at(p.dxoff(dir, i, b + 1));
         // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
-        CK(c.conv64(dxn, p.blk_wd[dir][2 * b + 1], nullptr, c.at(p.g1off(dir, i, b)), ACT_NONE, nullptr, c.at(p.aoff(dir, i, b)), MASK_RELU, n, h, w,
+        if (!chain) CK(c.conv64(dxn, p.blk_wd[dir][2 * b + 1], nullptr, c.at(p.g1off(dir, i, b)), ACT_NONE, nullptr, c.at(p.aoff(dir, i, b)), MASK_RELU, n, h, w,
                     nullptr, c.dtype == VSR_BF16 ? c.at(p.sboff(dir, i, b)) : nullptr));
         // dX_b = dX_{b+1} + dgrad(conv1)(dA); for b == 0 also through the stem's LeakyReLU
         void* out = b > 0 ? c.at(p.dxoff(dir, i, b)) : c.at(p.G0[dir][i]);

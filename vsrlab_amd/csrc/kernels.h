@@ -5,6 +5,24 @@
 int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar, int cout_t, int epi,
                     const ConvArgs& a, hipStream_t st);
 int vsr_launch_sign_bits_c64(const void* x_pm, void* bits, int N, int H, int W, hipStream_t st);     // conv3x3_persist.hip
+
+// ---- a chain of dependent 3x3 64 -> 64 layers in one launch (conv3x3_chain.hip) ----
+// Layer l reads `src`, writes `dst` (both whole blocked images of N x H x W x 64 bf16, each buffer written by exactly one layer of
+// the chain and read only by later layers).  Offsets are in units of 256 bytes from ChainArgs::base; 0xffffffff = none.
+enum { CHAIN_RELU = 0,     // dst = relu(conv(src) + bias), sign bits of dst -> sout (conv1 of a ResidualConv, conv.py:91)
+       CHAIN_SKIP = 1,     // dst = conv(src) + bias + res            (conv2 + identity, conv.py:92; dgrad(conv1) + dX)
+       CHAIN_MASK = 2 };   // dst = conv(src) * bit(sbits)            (dgrad(conv2) * ReLU')
+#define VSR_CHAIN_MAX_LAYERS 64
+struct ChainLayer { unsigned src, dst, res, sbits, sout, w, bias; int variant; };
+struct ChainArgs {
+    char* base;
+    unsigned* sync;              // vsr_chain_sync_bytes(): work counter, error word, row counters; zeroed by the launcher
+    int N, H, W, nlayers;
+    int cu_div;
+    ChainLayer layer[VSR_CHAIN_MAX_LAYERS];
+};
+size_t vsr_chain_sync_bytes(int nlayers, int N, int H);
+int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st);
 void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride);
 int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar, const WgradArgs& a, int nwg,
                      int* nslabs, hipStream_t st);      // *nslabs: partial slabs written (what the reduction sums)
