@@ -99,9 +99,72 @@ def flops_per_frame(h, w, t, rb):
     return f
 
 
-def dominant_kernel_roofline(dev, h, w, iters=48, nsets=8):
-    """conv3x3_c64_persist_kernel (bf16, 3x3, 64->64): the trunk/reconstruction conv and its data
-    gradient (>70% of the path's FLOPs).  Timed with HIP events on the stream it is launched on
+CHAIN_LAYERS, CHAIN_ITERS = 16, 12
+
+
+def dominant_kernel_roofline(dev, h, w):
+    """conv3x3_c64_chain_kernel (bf16): the residual-block convolutions of a frame -- 60 layers forward, 59 data gradients
+    backward -- run as ONE launch each inside the engine (csrc/conv3x3_chain.hip); ~40 % of a step's kernel time.  The leg
+    launches the same kernel through the C ABI (vsr_conv3x3_c64_chain_fwd) on CHAIN_LAYERS = 16 layers = 8 ResidualConv
+    blocks over 17 distinct 66 MB images (1.13 GB: every launch re-reads and re-writes all of them, so no image survives in
+    the 256 MiB Infinity Cache from one launch to the next; inside a launch layer l+1 reads what layer l has just written,
+    exactly as in the engine), timed with HIP events on the stream it is launched on.  Algorithmic bytes per launch (SURVEY
+    8d, per layer): X 64*P*2 + Y 64*P*2, + the identity 64*P*2 on every second layer.  The one-launch-per-layer kernel
+    (conv3x3_c64_persist, what the engine ran before round 3's chain and still runs for every other 3x3 64->64 layer) is
+    measured beside it, out of cache, under `per_layer_launch`."""
+    from vsrlab_amd import functional as VF
+    P = h * w
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ws = [(torch.randn(64, 64, 3, 3, generator=g) * 0.04).to(dev) for _ in range(CHAIN_LAYERS)]
+    bs = [torch.zeros(64, device=dev) for _ in range(CHAIN_LAYERS)]
+    ch = VF.ResidualChainC64(ws, bs, 1, h, w, dev)
+    ch.image(0).copy_(VF.to_pixel_major(torch.randn(1, 64, h, w, device=dev), VF.DT_BF16).reshape(-1))
+    for _ in range(2):
+        ch.launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(CHAIN_ITERS):
+        ch.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / CHAIN_ITERS
+    alg_bytes = sum((3 if l & 1 else 2) * 64 * P * 2 for l in range(CHAIN_LAYERS))
+    flops = 2.0 * P * 64 * 576 * CHAIN_LAYERS
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "traffic": None,
+           "kernel": f"conv3x3_c64_chain_kernel<CHAIN_RELU> ({CHAIN_LAYERS} layers = {CHAIN_LAYERS // 2} ResidualConv blocks per launch, "
+                     f"{CHAIN_LAYERS + 1} distinct 66 MB images)",
+           "avg_us": round(ms * 1e3, 2), "avg_us_per_layer": round(ms * 1e3 / CHAIN_LAYERS, 2), "layers_per_launch": CHAIN_LAYERS,
+           "algorithmic_bytes_per_launch": alg_bytes, "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+           "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+    del ch
+    out["per_layer_launch"] = per_layer_kernel_roofline(dev, h, w)
+    # Everything above was measured in THIS process.  The PMC counters cannot be (rocprofv3 passes are separate runs): they are
+    # replayed from the committed summary of the same command, under their own key and ONLY when that summary was produced from
+    # the kernel sources that are running now; `traffic` stays null otherwise.
+    tid = tree_id()
+    try:
+        pj = json.load(open(os.path.join(ROOT, PROFILE_JSON)))
+        src = {"file": PROFILE_JSON, "csrc_sha1": pj.get("csrc_sha1"), "git_head": pj.get("git_head"),
+               "measured_on": "the builder's gpurun box under rocprofv3, not in this run"}
+        if pj.get("csrc_sha1") == tid["csrc_sha1"]:
+            out["traffic"] = pj.get("hbm_bytes_per_launch")
+            for k in ("in_step", "mfma_busy", "in_kernel_clock_GHz", "roofline_leg_avg_us_rocprof"):
+                if k in pj:
+                    src[k] = pj[k]
+        else:
+            src["stale"] = "kernel sources differ from the profiled ones: counters not replayed"
+        out["counters_from"] = src
+    except Exception:
+        pass
+    return out
+
+
+def per_layer_kernel_roofline(dev, h, w, iters=48, nsets=8):
+    """conv3x3_c64_persist_kernel (bf16, 3x3, 64->64), one launch per layer: the reconstruction convs and every 3x3 64->64
+    layer outside the trunk chains.  Timed with HIP events on the stream it is launched on
     (torch's current stream), same shape and epilogues as inside the engine.  Algorithmic bytes per
     launch: X 64*P*2 + Y 64*P*2 (+ skip 64*P*2 on every second launch).
     The launches rotate through `nsets` = 8 distinct (x, skip, y) buffer sets = 1.6 GB at 540p, far beyond the 256 MiB
@@ -146,24 +209,6 @@ def dominant_kernel_roofline(dev, h, w, iters=48, nsets=8):
            "traffic": None, "kernel": "conv3x3_c64_persist_kernel<ACT,RES,MASK> (bias+ReLU / bias+skip alternating, 8 rotating 66 MB buffer sets)",
            "avg_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bytes, "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
-    # Everything above was measured in THIS process.  The PMC counters cannot be (rocprofv3 passes are separate runs): they are
-    # replayed from the committed summary of the same command, under their own key and ONLY when that summary was produced from
-    # the kernel sources that are running now; `traffic` stays null otherwise.
-    tid = tree_id()
-    try:
-        pj = json.load(open(os.path.join(ROOT, PROFILE_JSON)))
-        src = {"file": PROFILE_JSON, "csrc_sha1": pj.get("csrc_sha1"), "git_head": pj.get("git_head"),
-               "measured_on": "the builder's gpurun box under rocprofv3, not in this run"}
-        if pj.get("csrc_sha1") == tid["csrc_sha1"]:
-            out["traffic"] = pj.get("hbm_bytes_per_launch")
-            for k in ("in_step", "mfma_busy", "in_kernel_clock_GHz", "roofline_leg_avg_us_rocprof"):
-                if k in pj:
-                    src[k] = pj[k]
-        else:
-            src["stale"] = "kernel sources differ from the profiled ones: counters not replayed"
-        out["counters_from"] = src
-    except Exception:
-        pass
     return out
 
 

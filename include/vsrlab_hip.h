@@ -178,6 +178,22 @@ int vsr_pm_to_planar(int dtype, const void* in_pm, float* out, int N, int Cout, 
  * act: 0 none / 1 ReLU / 2 LeakyReLU(0.1); res_pm may be NULL.                               */
 int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float* b, void* wpack,
                         void* y_pm, const void* res_pm, int act, int N, int H, int W, void* stream);
+
+/* A chain of `nlayers` (2 x blocks, <= 64) dependent 3x3 64->64 convolutions in ONE launch: the body of ResidualBlock.res_block, a
+ * Sequential of ResidualConv (core/modules/conv.py:85-92, 99-103): x + conv2(relu(conv1(x))) per block.  What BasicVSR's two
+ * propagation branches run per frame behind their stem conv (basicvsr.py:56-58, 71-73), and with the flipped weight packs their
+ * data gradients.  The workgroups of the launch stay resident over all layers and hand finished 8x32-pixel tiles to each other
+ * through per-tile flags in `sync` (vsrlab_amd/csrc/conv3x3_chain.hip); results are bit-identical to nlayers calls of
+ * vsr_conv3x3_c64_fwd.  bf16 only.
+ *   images: nlayers + 1 consecutive blocked images of N x H x W x 64 bf16 (vsr_planar_to_pm layout): image 0 = x (input);
+ *           layer l reads image l and writes image l + 1.  Even l: act = ReLU(conv + bias); odd l: conv + bias + image l - 1
+ *           (the block's identity).  Every intermediate stays (the training layout: nothing is overwritten).
+ *   wpack : nlayers packed weight sets of 9*64*64 bf16 (as vsr_conv3x3_c64_fwd leaves them in its `wpack`), bias: nlayers x 64 fp32
+ *   sync  : vsr_conv3x3_c64_chain_sync_bytes(...) bytes of device scratch, owned by the launch until it has finished
+ * images, wpack and bias must be 256-byte aligned and within 1 TiB of each other (VSR_ERR_UNSUPPORTED otherwise).             */
+size_t vsr_conv3x3_c64_chain_sync_bytes(int nlayers, int N, int H, int W);
+int vsr_conv3x3_c64_chain_fwd(const void* images, const void* wpack, const float* bias, int nlayers, int N, int H, int W,
+                              void* sync, void* stream);
 /* dx = conv3x3_transpose(dy, w) (+res) (* mask(aux)): the data gradient of the same conv;
  * mask_mode: 0 none / 1 ReLU' of aux / 2 LeakyReLU' of aux                                   */
 int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm,

@@ -8,6 +8,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o rl -- python3 bench.py --roofline-only > $O/pmc_write.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o rl -- python3 bench.py --roofline-only > $O/pmc_mfma.log 2>&1 &&
 timeout -k 10 200 python tools/ab_conv.py 5 libvsrlab_hip.so libvsrlab_hip_conv3x3_persist_abl0.so > $O/clock.log 2>&1 &&
+timeout -k 10 200 python tools/ab_chain.py vsrlab_amd/lib/libvsrlab_hip.so vsrlab_amd/lib/libvsrlab_hip_conv3x3_chain_abl0.so > $O/clock_chain.log 2>&1 &&
 timeout -k 10 200 python tools/ab_wgrad.py 5 libvsrlab_hip.so libvsrlab_hip_wgrad_mfma_abl0.so > $O/clock_wgrad.log 2>&1 &&
 timeout -k 10 200 python tools/ab_c7.py 3 libvsrlab_hip.so libvsrlab_hip_conv7x7_persist_abl0.so > $O/clock_c7.log 2>&1 &&
 timeout -k 10 250 python bench.py --no-cpu-baseline --arena diet > $O/bench_diet.json 2> $O/bench_diet.err &&

@@ -18,8 +18,10 @@ import shutil
 import sys
 from collections import defaultdict
 
-KERN = "conv3x3_c64_persist_kernel"
+KERN = "conv3x3_c64_chain_kernel"          # the dominant kernel (round 3: the trunk chains); its leg: bench.py dominant_kernel_roofline
+KERN_LAYER = "conv3x3_c64_persist_kernel"   # one launch per layer (bench.py per_layer_kernel_roofline)
 P540 = 540 * 960
+CHAIN_LAYERS, CHAIN_ITERS = 16, 12          # bench.py
 
 
 def rows(path):
@@ -27,8 +29,8 @@ def rows(path):
         yield from csv.DictReader(f)
 
 
-def pmc_per_launch(d, counter, last=48):
-    """mean counter value over the LAST `last` persistent-conv dispatches (= the timed launches of the roofline leg)."""
+def pmc_per_launch(d, counter, last=CHAIN_ITERS):
+    """mean counter value over the LAST `last` chain dispatches (= the timed launches of the roofline leg)."""
     vals = defaultdict(float)
     order = []
     for r in rows(os.path.join(d, "rl_counter_collection.csv")):
@@ -57,28 +59,32 @@ def main():
                     out["csrc_sha1"], out["git_head"] = tree.get("csrc_sha1"), tree.get("git_head")
         except OSError:
             pass
-    # ---- in-kernel clock of the dominant kernel: tools/ab_conv.py with the ABL=0 diagnostic build (s_memtime / s_memrealtime around
+    # ---- in-kernel clock of the dominant kernel: tools/ab_chain.py with the ABL=0 diagnostic build (s_memtime / s_memrealtime around
     # the kernel, median over workgroups; MI355X_MICROARCH "DVFS give-back" item 6), same box and call as the traces ----
     try:
         import re
-        txt = open(os.path.join(src, "clock.log")).read()
-        m = {k: re.findall(k + r": clock ([0-9.]+) GHz", txt) for k in ("relu", "skip")}
-        if m["relu"] and m["skip"]:
-            out["in_kernel_clock_GHz_by_variant"] = {k: float(v[-1]) for k, v in m.items()}
-            out["in_kernel_clock_GHz"] = round(0.5 * (float(m["relu"][-1]) + float(m["skip"][-1])), 3)      # the leg alternates the two
+        m = re.findall(r"chain: clock ([0-9.]+) GHz", open(os.path.join(src, "clock_chain.log")).read())
+        if m:
+            out["in_kernel_clock_GHz"] = float(m[-1])
     except OSError:
         pass
-    # ---- roofline leg: its 48 timed launches are the last 48 persistent-conv rows of any trace of bench.py ----
-    tr = [r for r in rows(os.path.join(src, "trace1s", "bench_kernel_trace.csv")) if KERN in r["Kernel_Name"]]
-    tail = tr[-48:]
-    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tail]
+    # ---- roofline leg: its 12 timed launches are the last 12 chain rows of any trace of bench.py; the one-launch-per-layer leg
+    # behind it is the last 48 persistent-conv rows ----
+    allrows = list(rows(os.path.join(src, "trace1s", "bench_kernel_trace.csv")))
+    us = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tr = [r for r in allrows if KERN in r["Kernel_Name"]]
+    dur = [us(r) for r in tr[-CHAIN_ITERS:]]
     out["roofline_leg_avg_us_rocprof"] = round(sum(dur) / len(dur), 2)
+    out["roofline_leg_avg_us_per_layer_rocprof"] = round(sum(dur) / len(dur) / CHAIN_LAYERS, 2)
+    trl = [r for r in allrows if KERN_LAYER in r["Kernel_Name"]]
+    durl = [us(r) for r in trl[-48:]]
+    out["per_layer_launch_leg_avg_us_rocprof"] = round(sum(durl) / len(durl), 2)
     fetch, n1 = pmc_per_launch(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
     write, n2 = pmc_per_launch(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     out["fetch_size_kib_per_launch"] = round(fetch, 1)
     out["write_size_kib_per_launch"] = round(write, 1)
     out["hbm_bytes_per_launch"] = round((2.0 * fetch + write) * 1024.0)
-    out["algorithmic_bytes_per_launch"] = (64 + 64) * P540 * 2 + 0.5 * 64 * P540 * 2
+    out["algorithmic_bytes_per_launch"] = sum((3 if l & 1 else 2) * 64 * P540 * 2 for l in range(CHAIN_LAYERS))
     mf = {}
     for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
         try:
@@ -89,7 +95,7 @@ def main():
         mf = {k: round(v) for k, v in mf.items()}
         # SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 = FLOP (MI355X_MICROARCH cycle constants); the kernel's work is 2*P*64*576
         mf["flop_from_mops"] = mf.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) * 512
-        mf["flop_algorithmic"] = 2 * P540 * 64 * 576
+        mf["flop_algorithmic"] = 2 * P540 * 64 * 576 * CHAIN_LAYERS
         if "SQ_VALU_MFMA_BUSY_CYCLES" in mf:
             # busy cycles are summed over the chip's 1024 SIMDs.  GRBM_GUI_ACTIVE / 8 over-reads the clock on dispatches this
             # short (MI355X_MICROARCH, DVFS give-back), so the fraction is quoted against the in-kernel clock measured with
@@ -101,27 +107,19 @@ def main():
             mf["clock_GHz_used"] = ghz
         out["mfma_busy"] = mf
     # ---- the same kernel inside ONE timed step (single-stream trace: no overlap inflating durations) ----
-    # bench.py --steps 1 --warmup 1: the trace holds 2 steps, then the roofline leg (8 warm + 48 timed launches + 4 set-up)
-    body = tr[:-(48 + 8 + 4)]
-    step = body[len(body) // 2:]
-    by = defaultdict(list)
-    for r in step:
-        gx = int(r["Grid_Size_X"])
-        name = r["Kernel_Name"].split("kernel")[1].split("(")[0]             # "<ACT, RES, MASK[, PIPE]>"
-        name = "<" + ", ".join(x.strip() for x in name.strip("<>").split(",")[:3]) + ">"
-        by[(name, gx)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    # trunk-shape launches only (grid = 256 CUs x 512 threads over a 540x960 image is indistinguishable by grid size from
-    # the HR launches, so they are separated by duration: a 540p launch moves 133-199 MB, the HR ones 4-16x that)
-    alg = {"<1, false, 0>": 2 * 64 * P540 * 2, "<0, true, 0>": 3 * 64 * P540 * 2, "<0, false, 3>": 2 * 64 * P540 * 2 + 4.2e6}
-    tot_b = tot_t = 0.0
-    per = {}
-    for (name, gx), d in by.items():
-        if name in alg:
-            small = [x for x in d if x < 80.0]
-            per[name] = {"launches": len(small), "avg_us": round(sum(small) / max(len(small), 1), 2)}
-            tot_b += alg[name] * len(small)
-            tot_t += sum(small)
-    out["in_step"] = {"what": "540p trunk launches of conv3x3_c64_persist inside one timed step (single-stream trace), call-weighted",
+    # bench.py --steps 1 --warmup 1: the trace holds 2 steps (per step 14 forward chains <0> of 60 layers and 14 backward chains <2>
+    # of 59), then the roofline leg (2 warm + 12 timed launches of <0>)
+    fw = [r for r in tr if "<0>" in r["Kernel_Name"]][:-(CHAIN_ITERS + 2)]
+    bw = [r for r in tr if "<2>" in r["Kernel_Name"]]
+    fw, bw = fw[len(fw) // 2:], bw[len(bw) // 2:]
+    bits = 4.2e6                                   # sign bits of one 540p activation
+    alg_fw = 30 * ((2 + 3) * 64 * P540 * 2 + bits)
+    alg_bw = 30 * (2 * 64 * P540 * 2 + bits) + 29 * 3 * 64 * P540 * 2
+    tf, tb = sum(us(r) for r in fw), sum(us(r) for r in bw)
+    tot_b, tot_t = alg_fw * len(fw) + alg_bw * len(bw), tf + tb
+    per = {"forward chain <CHAIN_RELU>, 60 layers": {"launches": len(fw), "avg_us": round(tf / max(len(fw), 1), 1), "avg_us_per_layer": round(tf / max(len(fw), 1) / 60, 2)},
+           "backward chain <CHAIN_MASK>, 59 layers": {"launches": len(bw), "avg_us": round(tb / max(len(bw), 1), 1), "avg_us_per_layer": round(tb / max(len(bw), 1) / 59, 2)}}
+    out["in_step"] = {"what": "the trunk chains of conv3x3_c64_chain_kernel inside one timed step (single-stream trace), call-weighted",
                       "per_variant": per, "algorithmic_GBs": round(tot_b / tot_t / 1e3, 1), "frac_of_8TBs": round(tot_b / tot_t / 1e3 / 8000.0, 4)}
     json.dump(out, open(os.path.join(here, f"{tag}_roofline.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))

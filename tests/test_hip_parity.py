@@ -981,6 +981,36 @@ def test_trunk_chain_launch_is_bit_identical_to_one_launch_per_layer():
     assert _chain_timeouts() == t0
 
 
+@pytest.mark.parametrize("shape,blocks", [((2, 21, 70), 2), ((1, 96, 160), 5), ((1, 135, 240), 32)])
+def test_conv3x3_c64_chain_abi_matches_the_per_layer_calls(shape, blocks):
+    """vsr_conv3x3_c64_chain_fwd (functional.ResidualChainC64): 2 x blocks layers in one launch against the same layers as
+    2 x blocks calls of vsr_conv3x3_c64_fwd -- every intermediate image bit-identical, on a ragged batch of two, on a size
+    with more tiles than workgroups per layer... and on the maximum of 64 layers; launched twice (the flag words are
+    re-zeroed per launch)."""
+    dev = _gpu()
+    from vsrlab_amd import functional as VF
+    n, h, w = shape
+    L = 2 * blocks
+    ws = [rand(700 + l, 64, 64, 3, 3, lo=-1, hi=1) / 24.0 for l in range(L)]
+    bs = [rand(800 + l, 64, lo=-0.1, hi=0.1) for l in range(L)]
+    x = VF.to_pixel_major(rand(699, n, 64, h, w, lo=-1, hi=1).to(dev), VF.DT_BF16)
+    t0 = _chain_timeouts()
+    ch = VF.ResidualChainC64([t.to(dev) for t in ws], [t.to(dev) for t in bs], n, h, w, dev)
+    for rep in range(2):
+        y = ch(x)
+        cur, ref = x, [x]
+        for b in range(blocks):
+            a = VF.conv3x3_c64(cur, ws[2 * b].to(dev), bs[2 * b].to(dev), act=1)
+            cur = VF.conv3x3_c64(a, ws[2 * b + 1].to(dev), bs[2 * b + 1].to(dev), act=0, res_pm=cur)
+            ref += [a, cur]
+        valid = VF.from_pixel_major          # compare through the planar view: padding pixels of the blocked layout are never written
+        for l in range(1, L + 1):
+            got = ch.image(l).view(ref[l].shape)
+            got.pm_w = w
+            assert torch.equal(valid(got), valid(ref[l])), (shape, rep, l)
+    assert _chain_timeouts() == t0
+
+
 def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
     is process-wide, so they run in a child, like the pipelined-conv A/B above."""

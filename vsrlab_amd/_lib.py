@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvsrlab_hip.so")
+# VSRLAB_AMD_LIB: another build of the same library (the diagnostic `make ABL=...` / `make STAMPS=1` builds), for whole-step A/B runs
+LIB_PATH = os.environ.get("VSRLAB_AMD_LIB") or os.path.join(_HERE, "lib", "libvsrlab_hip.so")
 
 DT_F32 = 0
 DT_BF16 = 1
@@ -57,6 +58,8 @@ _SIGNATURES = {
     "vsr_planar_to_pm": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vsr_pm_to_planar": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv3x3_c64_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vsr_conv3x3_c64_chain_sync_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vsr_conv3x3_c64_chain_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "vsr_conv3x3_c64_dgrad": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv_layer_fwd": (c_int, [c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "vsr_conv_layer_bwd_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -43,6 +43,27 @@ constexpr int IN_CHUNKS = PNPIX * 8;
 constexpr int NPIECE_T = (IN_CHUNKS + 63) / 64;
 constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11; the leader wave (w4 = 0) always issues exactly 11
 
+// Diagnostic build only (make ABL=<bits> ABLSRC=conv3x3_chain; results may be WRONG, only the run time is read): bit 0: plain
+// instead of write-through stores; bit 1: plain instead of sc1 loads; bit 2: no dependency waits (every item counts as ready);
+// bit 3: no publishes; bit 4: no wait for the previous tile's stores at the top of an epilogue without operands.
+#ifdef VSR_ABL
+#define CABL(bit) ((VSR_ABL >> (bit)) & 1)
+__device__ unsigned long long g_clk_chain[256 * 2];      // [workgroup][cycles, 100 MHz ticks] of the last chain launch
+#else
+#define CABL(bit) 0
+#endif
+#if CABL(0)
+#define CH_SC1_ST ""
+#else
+#define CH_SC1_ST " sc1"
+#endif
+#if CABL(1)
+#define CH_SC1_LD ""
+#define CH_AUX 0
+#else
+#define CH_SC1_LD " sc1"
+#define CH_AUX 16
+#endif
 __device__ uint4 g_chain_zero_chunk[2];
 __device__ unsigned g_chain_timeouts;           // waits given up since the module was loaded (never reset: vsr_debug_chain_timeouts)
 
@@ -62,21 +83,28 @@ __device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) { unsi
 
 #define GLDS16_SC1(src, dst)                                                                          \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 16)
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, CH_AUX)
 #define GP(T, x) ((__attribute__((address_space(1))) T*)(x))
 
-// rows r-1, r, r+1 of one image's row counters (cnt points at row 0) have reached `target`; lanes 0..2 look at one row each
-__device__ __forceinline__ bool rows_ready(const gu32* cnt, int ty, int nty, unsigned target, int lane) {
+// The 3 x 3 tiles around (ty, tx) of one layer's image have been published by all four of their MFMA waves: flg points at the
+// image's first tile, one 16-byte record of four flag words per tile; lanes 0..8 look at one tile each (two 8-byte sc1 loads).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ bool halo_ready(const gu32* flg, int ty, int tx, int nty, int ntx, int lane) {
     bool ok = true;
-    const int r = ty - 1 + lane;
-    if (lane < 3 && r >= 0 && r < nty) ok = __hip_atomic_load(cnt + r, RLX_AGENT) >= target;
+    const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
+    const int y = ty + dy, x = tx + dx;
+    if (lane < 9 && y >= 0 && y < nty && x >= 0 && x < ntx) {
+        const gu64* f = reinterpret_cast<const gu64*>(flg) + 2 * (long long)(y * ntx + x);
+        const unsigned long long a = __hip_atomic_load(f, RLX_AGENT), b = __hip_atomic_load(f + 1, RLX_AGENT);
+        ok = a == 0x0000000100000001ull && b == 0x0000000100000001ull;
+    }
     return __all(ok);
 }
 // the slow path of a consumer: poll until ready; false = gave up (the error word is set: results are void)
-__device__ __forceinline__ bool rows_wait(const gu32* cnt, int ty, int nty, unsigned target, int lane, gu32* err) {
+__device__ __forceinline__ bool halo_wait(const gu32* flg, int ty, int tx, int nty, int ntx, int lane, gu32* err) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        if (rows_ready(cnt, ty, nty, target, lane)) return true;
+        if (halo_ready(flg, ty, tx, nty, ntx, lane)) return true;
         if (__hip_atomic_load(err, RLX_AGENT) != 0u) return false;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {                // 1 s of the 100 MHz clock
             if (lane == 0) { __hip_atomic_fetch_add(err, 1u, RLX_AGENT); __hip_atomic_fetch_add(GP(unsigned, &g_chain_timeouts), 1u, RLX_AGENT); }
@@ -101,16 +129,19 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
 
     const int H = ka.H, W = ka.W;
     const int ntx = cdiv(W, PTW), nty = cdiv(H, PTH);
-    const int per = ntx * nty, tiles = ka.N * per, rows = ka.N * nty;
+    const int per = ntx * nty, tiles = ka.N * per;
     const int total = tiles * ka.nlayers;
     const int WS = pm_ws(W);
     const long long img = pm_image_elems(H, W, 64);
     char* const base = ka.base;
     gu32* const work = GP(unsigned, ka.sync);
     gu32* const err = work + 1;
-    gu32* const cnt0 = work + 16;                                          // [layer][rows]
-    const unsigned target = 4u * (unsigned)ntx;
+    gu32* const flg0 = work + 64;                                          // [item = layer * tiles + tile][4 MFMA waves]
 
+#ifdef VSR_ABL
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (tid == 0) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     // ---- the first two items of this workgroup ----
     if (tid == 256) {
         const int v = (int)__hip_atomic_fetch_add(work, 2u, RLX_AGENT);
@@ -120,7 +151,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             int* sl = ctl + 8 * s;
             if (it < total) {
                 const int l = it / tiles, r = it - l * tiles, n = r / per, r2 = r - n * per, ty = r2 / ntx;
-                sl[0] = it; sl[1] = l; sl[2] = n; sl[3] = ty; sl[4] = r2 - ty * ntx; sl[5] = l == 0 ? 1 : 0;
+                sl[0] = it; sl[1] = l; sl[2] = n; sl[3] = ty; sl[4] = r2 - ty * ntx; sl[5] = (l == 0 || CABL(2)) ? 1 : 0;
             } else {
                 sl[0] = -1; sl[1] = 0; sl[2] = 0; sl[3] = 0; sl[4] = 0; sl[5] = 0;
             }
@@ -185,7 +216,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
         // item 0: nothing was polled for it yet
         {
             const int l0 = ctl[1], n0 = ctl[2], ty0 = ctl[3], tx0 = ctl[4];
-            if (l0 > 0) (void)rows_wait(cnt0 + (long long)(l0 - 1) * rows + (long long)n0 * nty, ty0, nty, target, lane, err);
+            if (l0 > 0 && !CABL(2)) (void)halo_wait(flg0 + 4 * ((long long)(l0 - 1) * tiles + (long long)n0 * per), ty0, tx0, nty, ntx, lane, err);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             issue(l0, n0, ty0, tx0, 0);
         }
@@ -196,6 +227,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             const int* sc = ctl + 8 * (k % 3);
             if (sc[0] < 0) break;
             const int layer_k = __builtin_amdgcn_readfirstlane(sc[1]);
+            // The MFMA waves' weight reload of a layer change: joined FIRST.  Behind the dependency wait below it would deadlock:
+            // the MFMA waves would sit in this barrier in front of tile k while the wait is for tile k-1's deferred publish,
+            // which they make in tile k's epilogue.
+            if (layer_k != cur_layer) { cur_layer = layer_k; __syncthreads(); }
             int* s1 = ctl + 8 * ((k + 1) % 3);
             const int it1 = __builtin_amdgcn_readfirstlane(s1[0]);
             // the leader asks for item k+2 first: the atomic's round trip runs under the poll / DMA issue below
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 const int l1 = __builtin_amdgcn_readfirstlane(s1[1]), n1 = __builtin_amdgcn_readfirstlane(s1[2]);
                 const int ty1 = __builtin_amdgcn_readfirstlane(s1[3]), tx1 = __builtin_amdgcn_readfirstlane(s1[4]);
                 if (__builtin_amdgcn_readfirstlane(s1[5]) == 0) {
-                    (void)rows_wait(cnt0 + (long long)(l1 - 1) * rows + (long long)n1 * nty, ty1, nty, target, lane, err);
+                    (void)halo_wait(flg0 + 4 * ((long long)(l1 - 1) * tiles + (long long)n1 * per), ty1, tx1, nty, ntx, lane, err);
                     if (leader && lane == 0) s1[5] = 1;   // tells the MFMA waves that their deferred publish cannot be what we wait for
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -227,12 +262,11 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                         l2 = it2 / tiles; const int r = it2 - l2 * tiles; n2 = r / per; const int r2 = r - n2 * per; ty2 = r2 / ntx; tx2 = r2 - ty2 * ntx;
                         // its dependencies, looked at now, used a barrier later (the result returns behind this wave's DMA pieces,
                         // i.e. under the wait for the tile that is needed anyway)
-                        ok2 = l2 == 0 || rows_ready(cnt0 + (long long)(l2 - 1) * rows + (long long)n2 * nty, ty2, nty, target, lane);
+                        ok2 = l2 == 0 || CABL(2) || halo_ready(flg0 + 4 * ((long long)(l2 - 1) * tiles + (long long)n2 * per), ty2, tx2, nty, ntx, lane);
                     }
                 }
                 if (lane == 0) { s2[0] = it2; s2[1] = l2; s2[2] = n2; s2[3] = ty2; s2[4] = tx2; s2[5] = ok2 ? 1 : 0; }
             }
-            if (layer_k != cur_layer) { cur_layer = layer_k; __syncthreads(); }     // the MFMA waves' weight reload
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
         layer_ptrs(cur_layer);
 
         bool pending = false;                 // a finished tile of this wave whose row counter has not been told yet
-        gu32* pend_cnt = nullptr;
+        gu32* pend_cnt = nullptr;             // its flag word: flags[item][w4]
         int cur = 0;
         // item k of this workgroup (slot k % 3); the next slot is read at the top of a tile and used at its end
         int item = __builtin_amdgcn_readfirstlane(ctl[0]), layer = cur_layer, tn = __builtin_amdgcn_readfirstlane(ctl[2]);
@@ -317,7 +351,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             bool ok[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) ok[nb] = (tx0 + (nb & 1) * 16 + pxl < W) && (ty0 + w4 * 2 + (nb >> 1) < H);
-            gu32* const my_cnt = cnt0 + (long long)layer * rows + (long long)tn * nty + tyi;
+            gu32* const my_cnt = flg0 + 4 * (long long)item + w4;
 
             auto body = [&](auto VC) {
                 constexpr int V = decltype(VC)::value;
@@ -334,14 +368,14 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                         // (inline asm is not padded by hipcc: `s_nop 4` = the wait states between the scalar adds that made rbase and a
                         // vector-memory instruction using it as its base; cdna_hip_programming.md 5.7 item 2)
                         if (full) {
-                            if (nb == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
-                            else asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
-                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 sc1" : "=v"(rr[1][nb]) : "v"(lo), "s"(rbase) : "memory");
+                            if (nb == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" CH_SC1_LD : "=v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
+                            else asm volatile("global_load_dwordx4 %0, %1, %2" CH_SC1_LD : "=v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
+                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" CH_SC1_LD : "=v"(rr[1][nb]) : "v"(lo), "s"(rbase) : "memory");
                         } else {
                             rr[0][nb] = u32x4_t{0u, 0u, 0u, 0u}; rr[1][nb] = u32x4_t{0u, 0u, 0u, 0u};
                             if (ok[nb]) {
-                                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "+v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
-                                asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 sc1" : "+v"(rr[1][nb]) : "v"(lo), "s"(rbase) : "memory");
+                                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" CH_SC1_LD : "+v"(rr[0][nb]) : "v"(lo), "s"(rbase) : "memory");
+                                asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" CH_SC1_LD : "+v"(rr[1][nb]) : "v"(lo), "s"(rbase) : "memory");
                             }
                         }
                     }
@@ -398,10 +432,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 // now its row counter may be told (R1: every storing wave drains, then adds for itself)
                 // (the builtin, so that hipcc's scoreboard knows the queue is empty: behind an asm wait it would wait again, for the
                 // publishing atomic below, in front of the first use of the sign bits)
-                __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0) alone
+                if (!(CABL(4) && V == CHAIN_RELU)) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) alone
                 __builtin_amdgcn_sched_barrier(0);
                 if (pending) {
-                    if (lane == 0) __hip_atomic_fetch_add(pend_cnt, 1u, RLX_AGENT);
+                    if (lane == 0 && !CABL(3)) __hip_atomic_store(pend_cnt, 1u, RLX_AGENT);
                     pending = false;
                 }
                 if constexpr (HAS_RES) {
@@ -446,9 +480,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                                 // (asm: `s_nop 1` behind a 16-byte store, or hipcc's next instruction may overwrite the data registers before
                                 // the store has read them; `s_nop 4` in front of the first user of the freshly added base; 5.7 items 1, 2)
                                 if (kq == 0) {
-                                    if (nb == 0 || !decltype(FULL)::value) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
-                                    else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
-                                } else asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 sc1\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
+                                    if (nb == 0 || !decltype(FULL)::value) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" CH_SC1_ST "\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
+                                    else asm volatile("global_store_dwordx4 %0, %1, %2" CH_SC1_ST "\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
+                                } else asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048" CH_SC1_ST "\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
                             }
                         }
                     }
@@ -464,7 +498,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             // already seen that tile's dependencies complete, drain and publish now.
             if (nx_item < 0 || nx_ok == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(pend_cnt, 1u, RLX_AGENT);
+                if (lane == 0 && !CABL(3)) __hip_atomic_store(pend_cnt, 1u, RLX_AGENT);
                 pending = false;
             }
             __syncthreads();                               // the next tile has landed; everybody has finished reading `cur`
@@ -473,17 +507,29 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             tyi = __builtin_amdgcn_readfirstlane(nx_ty); txi = __builtin_amdgcn_readfirstlane(nx_tx);
         }
     }
+#ifdef VSR_ABL
+    if (tid == 0 && blockIdx.x < 256) {
+        g_clk_chain[blockIdx.x * 2 + 0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_clk_chain[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef VSR_ABL
+extern "C" int vsr_debug_read_clk_chain(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clk_chain), sizeof(unsigned long long) * 256 * 2) == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+#endif
 
 // dependency waits that were given up (1 s each) since the library was loaded: anything but 0 voids the results of that run
 extern "C" int vsr_debug_chain_timeouts(unsigned* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_timeouts), sizeof(unsigned)) == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
-size_t vsr_chain_sync_bytes(int nlayers, int N, int H) {
-    return ((size_t)(16 + (size_t)nlayers * N * cdiv(H, PTH)) * 4 + 255) & ~(size_t)255;
+size_t vsr_chain_sync_bytes(int nlayers, int N, int H, int W) {
+    return 256 + (size_t)nlayers * N * cdiv(H, PTH) * cdiv(W, PTW) * 16;
 }
 
 // a.sync: vsr_chain_sync_bytes() of device memory owned by this launch until it has finished (zeroed here, on the stream)
@@ -503,7 +549,7 @@ int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st) {
     auto kern = even == CHAIN_MASK ? conv3x3_c64_chain_kernel<CHAIN_MASK> : conv3x3_c64_chain_kernel<CHAIN_RELU>;
     static VsrDevOnce once[2];
     { const int rc = vsr_set_max_dynamic_lds(once[even == CHAIN_MASK], reinterpret_cast<const void*>(kern), P_LDS); if (rc != VSR_OK) return rc; }
-    HIP_CHECK_RET(hipMemsetAsync(a.sync, 0, vsr_chain_sync_bytes(a.nlayers, a.N, a.H), st));
+    HIP_CHECK_RET(hipMemsetAsync(a.sync, 0, vsr_chain_sync_bytes(a.nlayers, a.N, a.H, a.W), st));
     int gx = num_cus / (a.cu_div > 1 ? a.cu_div : 1);
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = (int)tiles;

@@ -216,7 +216,7 @@ struct Plan {
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
         }
         // the trunk chains' work / row counters (conv3x3_chain.hip), one block per direction (= per stream)
-        for (int dir = 0; dir < 2; ++dir) chain_sync[dir] = (bwd && !diet && dtype == VSR_BF16) ? b.take(vsr_chain_sync_bytes(VSR_CHAIN_MAX_LAYERS, n, h)) : 0;
+        for (int dir = 0; dir < 2; ++dir) chain_sync[dir] = (bwd && !diet && dtype == VSR_BF16) ? b.take(vsr_chain_sync_bytes(VSR_CHAIN_MAX_LAYERS, n, h, w)) : 0;
         // appended last, so that every other offset is the same in modes 1 and 2
         dflows = 0;
         if (flowgrad && t > 1) {
@@ -1318,6 +1318,39 @@ int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float
     ConvArgs a = plain64(x_pm, wpack, b, y_pm, N, H, W);
     a.act = act; a.res[0] = res_pm;
     return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+}
+
+size_t vsr_conv3x3_c64_chain_sync_bytes(int nlayers, int N, int H, int W) {
+    if (nlayers < 1 || nlayers > VSR_CHAIN_MAX_LAYERS || bad_dims(N, H, W)) return 0;
+    return vsr_chain_sync_bytes(nlayers, N, H, W);
+}
+
+int vsr_conv3x3_c64_chain_fwd(const void* images, const void* wpack, const float* bias, int nlayers, int N, int H, int W, void* sync,
+                              void* stream) {
+    if (!images || !wpack || !bias || !sync || nlayers < 1 || nlayers > VSR_CHAIN_MAX_LAYERS || bad_dims(N, H, W)) return VSR_ERR_BADARG;
+    const size_t img = (size_t)N * pm_image_elems(H, W, C) * 2, wset = (size_t)9 * C * C * 2;
+    // the kernel addresses every operand as a 32-bit offset (x 256 B) from one base
+    uintptr_t lo = (uintptr_t)images;
+    if ((uintptr_t)wpack < lo) lo = (uintptr_t)wpack;
+    if ((uintptr_t)bias < lo) lo = (uintptr_t)bias;
+    lo &= ~(uintptr_t)255;
+    auto off = [&](const void* p, size_t add, unsigned* out) {
+        const uintptr_t d = (uintptr_t)p + add - lo;
+        if ((d & 255) || (d >> 8) >= 0xffffffffull) return false;
+        *out = (unsigned)(d >> 8);
+        return true;
+    };
+    ChainArgs a = {};
+    a.base = (char*)lo; a.sync = (unsigned*)sync; a.N = N; a.H = H; a.W = W; a.nlayers = nlayers; a.cu_div = 1;
+    for (int l = 0; l < nlayers; ++l) {
+        ChainLayer& L = a.layer[l];
+        L = {0, 0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, (l & 1) ? CHAIN_SKIP : CHAIN_RELU};
+        bool ok = off(images, (size_t)l * img, &L.src) && off(images, (size_t)(l + 1) * img, &L.dst) && off(wpack, (size_t)l * wset, &L.w) &&
+                  off(bias, (size_t)l * C * 4, &L.bias);
+        if (l & 1) ok = ok && off(images, (size_t)(l - 1) * img, &L.res);
+        if (!ok) return VSR_ERR_UNSUPPORTED;
+    }
+    return vsr_launch_conv3x3_chain(a, vsr_num_cus(), (hipStream_t)stream);
 }
 
 int vsr_conv3x3_c64_dgrad(int dtype, const void* dy_pm, const float* w, void* wpack, void* dx_pm, const void* res_pm,

@@ -16,12 +16,12 @@ enum { CHAIN_RELU = 0,     // dst = relu(conv(src) + bias), sign bits of dst -> 
 struct ChainLayer { unsigned src, dst, res, sbits, sout, w, bias; int variant; };
 struct ChainArgs {
     char* base;
-    unsigned* sync;              // vsr_chain_sync_bytes(): work counter, error word, row counters; zeroed by the launcher
+    unsigned* sync;              // vsr_chain_sync_bytes(): work counter, error word, one flag word per (layer, tile, MFMA wave); zeroed by the launcher
     int N, H, W, nlayers;
     int cu_div;
     ChainLayer layer[VSR_CHAIN_MAX_LAYERS];
 };
-size_t vsr_chain_sync_bytes(int nlayers, int N, int H);
+size_t vsr_chain_sync_bytes(int nlayers, int N, int H, int W);
 int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st);
 void vsr_wgrad_slab_dims(int ks, int cx, int cout, int* coutp, int* cxp, int* stride);
 int vsr_launch_wgrad(int dtype, int ks, int cx, int x_planar, int cout, int dy_planar, const WgradArgs& a, int nwg,

@@ -162,6 +162,53 @@ def conv3x3_c64(x_pm: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return y
 
 
+class ResidualChainC64:
+    """The body of ResidualBlock.res_block (conv.py:85-92, 99-103) as ONE launch (vsr_conv3x3_c64_chain_fwd): `blocks`
+    ResidualConv blocks on a blocked 64-channel bf16 image, every intermediate kept.  Holds one allocation with the
+    2*blocks + 1 images, the packed weights, the biases and the launch's flag words; call it with x_pm to run the chain,
+    `image(l)` is layer l's input (image(2*blocks) = the output)."""
+
+    def __init__(self, weights, biases, n: int, h: int, w: int, device):
+        assert len(weights) == len(biases) and len(weights) >= 1
+        lib = _lib.load()
+        self.L, self.n, self.h, self.w = len(weights), n, h, w
+        self.img_elems = n * h * ((w + 31) // 32) * 32 * 64
+        al = lambda b: (b + 255) // 256 * 256
+        o_w = al((self.L + 1) * self.img_elems * 2)
+        o_b = o_w + al(self.L * 9 * 64 * 64 * 2)
+        o_s = o_b + al(self.L * 64 * 4)
+        nsync = lib.vsr_conv3x3_c64_chain_sync_bytes(self.L, n, h, w)
+        if nsync == 0:
+            raise ValueError("vsrlab_amd: unsupported chain shape")
+        self.buf = torch.zeros(o_s + nsync + 512, dtype=torch.uint8, device=device)
+        pad = (-self.buf.data_ptr()) % 256
+        self.buf = self.buf[pad:]
+        self.images = self.buf[:(self.L + 1) * self.img_elems * 2].view(torch.bfloat16)
+        self.wpack = self.buf[o_w:o_w + self.L * 9 * 64 * 64 * 2].view(torch.bfloat16)
+        self.bias = self.buf[o_b:o_b + self.L * 64 * 4].view(torch.float32)
+        self.sync = self.buf[o_s:o_s + nsync]
+        scratch = torch.empty(self.img_elems, dtype=torch.bfloat16, device=device)
+        for l, (wt, b) in enumerate(zip(weights, biases)):          # vsr_conv3x3_c64_fwd packs a weight set as a side effect
+            _lib.check(lib.vsr_conv3x3_c64_fwd(DT_BF16, _ptr(self.image(0)), _ptr(_f32c(wt)), _ptr(None), _ptr(self.wpack[l * 9 * 64 * 64:]),
+                                               _ptr(scratch), _ptr(None), 0, n, h, w, _stream()), "conv3x3_c64_fwd")
+            self.bias[l * 64:(l + 1) * 64] = 0.0 if b is None else _f32c(b)
+
+    def image(self, l: int) -> torch.Tensor:
+        return self.images[l * self.img_elems:(l + 1) * self.img_elems]
+
+    def launch(self):
+        lib = _lib.load()
+        _lib.check(lib.vsr_conv3x3_c64_chain_fwd(_ptr(self.images), _ptr(self.wpack), _ptr(self.bias), self.L, self.n, self.h, self.w,
+                                                 _ptr(self.sync), _stream()), "conv3x3_c64_chain_fwd")
+
+    def __call__(self, x_pm: torch.Tensor) -> torch.Tensor:
+        _require_gpu(x_pm)
+        assert x_pm.dtype == torch.bfloat16 and x_pm.numel() == self.img_elems
+        self.image(0).copy_(x_pm.reshape(-1))
+        self.launch()
+        return self.image(self.L)
+
+
 def conv3x3_c64_dgrad(dy_pm: torch.Tensor, weight: torch.Tensor, res_pm: Optional[torch.Tensor] = None,
                       aux_pm: Optional[torch.Tensor] = None, mask_mode: int = 0) -> torch.Tensor:
     _require_gpu(dy_pm, weight)
