@@ -191,6 +191,7 @@ int vsr_conv3x3_c64_fwd(int dtype, const void* x_pm, const float* w, const float
  *   wpack : nlayers packed weight sets of 9*64*64 bf16 (as vsr_conv3x3_c64_fwd leaves them in its `wpack`), bias: nlayers x 64 fp32
  *   sync  : vsr_conv3x3_c64_chain_sync_bytes(...) bytes of device scratch, owned by the launch until it has finished
  * images, wpack and bias must be 256-byte aligned and within 1 TiB of each other (VSR_ERR_UNSUPPORTED otherwise).             */
+/* (ABI 4) */
 size_t vsr_conv3x3_c64_chain_sync_bytes(int nlayers, int N, int H, int W);
 int vsr_conv3x3_c64_chain_fwd(const void* images, const void* wpack, const float* bias, int nlayers, int N, int H, int W,
                               void* sync, void* stream);

@@ -112,7 +112,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     loaded = _lib.load()                                 # sets argtypes for every export
-    assert loaded.vsr_abi_version() == 3
+    assert loaded.vsr_abi_version() == 4
     assert loaded.vsr_status_string(-4) == b"workspace too small"
 
 

@@ -3,27 +3,35 @@
 //
 // Why: a 540p layer is 2040 tiles of 8x32 pixels = 8 per CU.  As its own launch (conv3x3_persist.hip) a layer pays ~6.4 k
 // cycles of prologue (kernel arguments, 72 KiB of weights, the first tile's HBM round trip) and ~6 us of launch / drain around 8 x
-// 6.1 k cycles of tiles: a quarter of the 38-45 us a layer takes.  Here the workgroups stay resident over all layers of the
-// chain; a layer boundary costs a workgroup one weight reload, and nobody waits for the slowest workgroup of a layer.
+// 6.1 k cycles of tiles.  Here the workgroups stay resident over all layers of the chain; a layer boundary costs a workgroup one
+// weight reload, and nobody waits for the slowest workgroup of a layer.  What it buys, measured: 58.6 k cycles per
+// workgroup and layer instead of ~66 k -- but the chip answers the denser MFMA stream with a lower clock (1.5 against 1.75-1.9
+// GHz in the one-layer kernel; MI355X_MICROARCH "DVFS give-back" item 3), so a layer takes ~40 us either way out of cache and
+// the step gains 2 % (the two-stream engine already hid most of the per-launch gaps).  Energy per tile, not idle time, is what
+// bounds this convolution on this chip.
 //
 // How the layers are ordered without a grid barrier:
-//   * work items = (layer, tile) in layer-major, row-major order, handed out by ONE global atomic counter.  An item depends only
-//     on items with smaller indices (the 3x3 halo: tile rows r-1, r, r+1 of the previous layer), and an item is only ever taken
-//     by a RUNNING workgroup, which works through its items in order: the smallest unfinished item can always proceed, whatever
-//     share of the grid is resident (the engine's second stream may hold CUs; two chains may run side by side).
 //   * a finished tile is PUBLISHED per MFMA wave: outputs are stored write-through (global_store ... sc1: the per-XCD L2s are not
-//     coherent), the wave waits for its stores (s_waitcnt vmcnt(0)), then one lane adds 1 to the counter of (layer, tile row):
-//     a row is complete at 4 waves x tiles-per-row.  MI355X_MICROARCH "inter-workgroup visibility", the row "each storing wave
-//     for itself / sc1 poll / workgroup barrier between the poll and every load".  The add is DEFERRED to the top of the wave's
-//     next epilogue, where the stores have long been acknowledged -- unless the workgroup's next item is not known to be ready
-//     (then the wave drains and publishes at once: on small images the next item can depend on this one).
-//   * consumers: the leader producer wave polls the three row counters of an item two tiles ahead (relaxed agent-scope loads)
-//     and leaves the verdict in LDS; a workgroup barrier later the producer waves issue the tile's LDS-DMA (sc1: bypasses the
-//     CU's L1).  Not ready at that point -> every producer wave polls for itself (bounded by a 1 s clock; a timeout raises a
-//     global error word that ends every wait, so the grid always drains, and the host refuses the result).  The residual operand
-//     of a layer is the output of the layer before the previous one at the same tile: complete by transitivity, loaded sc1.
-//   * every buffer of a chain is written exactly once and read only after its row counters say so (training arena: one buffer
-//     per layer), so no CU can hold a stale line of it.
+//     coherent), the wave waits for its stores (s_waitcnt vmcnt(0)), then one lane stores 1 into the wave's flag word of the tile
+//     (sc1): flags[item][wave], 16 bytes per tile.  MI355X_MICROARCH "inter-workgroup visibility": payload sc1, every storing
+//     wave drains, flag written sc1, consumer polls sc1.  (Row COUNTERS instead of flags -- 120 atomic adds per tile row -- cost
+//     30 ms per step: same-line atomics serialise at the memory side and sit in the waves' in-order vmcnt queues.)  The flag
+//     store is DEFERRED to the top of the wave's next epilogue, where the stores have long been acknowledged -- unless the
+//     workgroup's next item is not known to be ready (then the wave drains and publishes at once: on small images the next item
+//     can depend on this one).
+//   * consumers: the leader producer wave looks at the flags of the 3x3 tiles around an item two tiles ahead (nine lanes, two
+//     8-byte sc1 loads each) and leaves the verdict in LDS; a workgroup barrier later the producer waves issue the tile's LDS-DMA
+//     (sc1: bypasses the CU's L1).  Not ready at that point -> every producer wave polls for itself (bounded by a 1 s clock; a
+//     timeout raises a global error word that ends every wait, so the grid always drains; vsr_debug_chain_timeouts counts them
+//     and the tests require 0).  The residual operand of a layer is the output of the layer before the previous one at the same
+//     tile: complete by transitivity, loaded sc1.
+//   * every buffer of a chain is written exactly once and read only after its flags say so (training arena: one buffer per
+//     layer), so no CU can hold a stale line of it.
+//   * work distribution and the progress argument: "Work distribution" below.
+//
+// Inline-asm notes (both cost a wrong result each before they were in): a 16-byte asm store ends in `s_nop 1` (hipcc's next
+// instruction may otherwise overwrite the data registers before the store has read them) and the first vector-memory asm
+// behind the scalar adds of its base starts with `s_nop 4` (cdna_hip_programming.md 5.7).
 //
 // The tile loop itself (K loop, fragment schedule, epilogues) is conv3x3_persist.hip's; see there for the LDS images.
 #include "common.h"
@@ -114,6 +122,43 @@ __device__ __forceinline__ bool halo_wait(const gu32* flg, int ty, int tx, int n
     }
 }
 
+// Work distribution.  A layer's tiles are split into R = 8 contiguous regions, one per XCD (workgroup b runs on XCD b % 8: the
+// tiles a region's workgroups load at the same time are neighbours, so their halos are served by that XCD's L2, as with
+// xcd_tile_walk in the one-layer kernel).  Each region has ONE hand-out counter for the whole chain: position P of region r is
+// tile chain_region_tile(P % size_r) of layer P / size_r, so a fetch is a single atomic and a workgroup's items never go back a
+// layer.  Progress: take the unfinished item m of the lowest layer.  Everything in lower layers is finished, so every TAKEN item
+// of m's layer can complete; the workgroups of m's region work through the region's positions in order, so they reach m -- as
+// long as every region has a workgroup that is or becomes resident, i.e. as long as no other kernel that waits for THIS one
+// holds its CUs: the engine therefore runs its chain launches on one stream.  (R = 1, one counter = one global order, when the
+// grid is not a multiple of 8 workgroups.)
+__device__ __forceinline__ int chain_rlo(int r, int tiles, int R) { return (int)((long long)r * tiles / R); }
+// The p-th tile handed out of a region of `sz` tiles: chunks of `ntx` consecutive tiles (about one tile row), taken MIDDLE-OUT
+// (m, m+1, m-1, m+2, ...).  In the next layer a chunk needs its neighbour chunks of this layer (the 3x3 halo): with the same
+// order in every layer those were handed out a whole layer earlier, also across region borders, whose chunks come last --
+// top-to-bottom, the first chunk of every region would wait for the previous region's LAST chunk of the layer before.
+__device__ __forceinline__ int chain_region_tile(int p, int sz, int ntx) {
+    const int nch = (sz + ntx - 1) / ntx, m = nch >> 1, D = m, U = nch - 1 - m;
+    const int lim = 2 * (U < D ? U : D);
+    for (int sq = 0; sq < nch; ++sq) {
+        int c;
+        if (sq == 0) c = m;
+        else if (sq <= lim) c = (sq & 1) ? m + ((sq + 1) >> 1) : m - (sq >> 1);
+        else c = U > D ? m + (sq - D) : m - (sq - U);
+        const int c0 = c * ntx, cn = (c0 + ntx <= sz ? ntx : sz - c0);
+        if (p < cn) return c0 + p;
+        p -= cn;
+    }
+    return sz - 1;      // (not reached for p < sz)
+}
+// position P of region `own` -> item (layer * tiles + tile), or -1 behind the last layer
+__device__ __forceinline__ int chain_item(unsigned P, int own, int R, int tiles, int ntx, int nlayers) {
+    const int lo = chain_rlo(own, tiles, R), sz = chain_rlo(own + 1, tiles, R) - lo;
+    if (sz <= 0) return -1;
+    const int l = (int)(P / (unsigned)sz);
+    if (l >= nlayers) return -1;
+    return l * tiles + lo + chain_region_tile((int)(P - (unsigned)l * (unsigned)sz), sz, ntx);
+}
+
 // EVEN: the variant of the chain's layers that are not CHAIN_SKIP (forward chains: CHAIN_RELU, backward chains: CHAIN_MASK)
 template <int EVEN>
 __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainArgs ka) {
@@ -130,13 +175,15 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
     const int H = ka.H, W = ka.W;
     const int ntx = cdiv(W, PTW), nty = cdiv(H, PTH);
     const int per = ntx * nty, tiles = ka.N * per;
-    const int total = tiles * ka.nlayers;
     const int WS = pm_ws(W);
     const long long img = pm_image_elems(H, W, 64);
     char* const base = ka.base;
     gu32* const work = GP(unsigned, ka.sync);
     gu32* const err = work + 1;
-    gu32* const flg0 = work + 64;                                          // [item = layer * tiles + tile][4 MFMA waves]
+    const int R = (gridDim.x >= 8 && (gridDim.x & 7) == 0) ? 8 : 1;
+    const int own = R == 8 ? (int)(blockIdx.x & 7) : 0;
+    gu32* const qown = work + 64 + 16 * own;                               // this region's hand-out counter (a 64-byte line of its own)
+    gu32* const flg0 = work + 256;                                         // [item = layer * tiles + tile][4 MFMA waves]
 
 #ifdef VSR_ABL
     unsigned long long clk_t0 = 0, clk_r0 = 0;
@@ -144,12 +191,12 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
 #endif
     // ---- the first two items of this workgroup ----
     if (tid == 256) {
-        const int v = (int)__hip_atomic_fetch_add(work, 2u, RLX_AGENT);
+        const unsigned v = __hip_atomic_fetch_add(qown, 2u, RLX_AGENT);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int it = v + s;
-            int* sl = ctl + 8 * s;
-            if (it < total) {
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int it = chain_item(v + sidx, own, R, tiles, ntx, ka.nlayers);
+            int* sl = ctl + 8 * sidx;
+            if (it >= 0) {
                 const int l = it / tiles, r = it - l * tiles, n = r / per, r2 = r - n * per, ty = r2 / ntx;
                 sl[0] = it; sl[1] = l; sl[2] = n; sl[3] = ty; sl[4] = r2 - ty * ntx; sl[5] = (l == 0 || CABL(2)) ? 1 : 0;
             } else {
@@ -235,8 +282,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             const int it1 = __builtin_amdgcn_readfirstlane(s1[0]);
             // the leader asks for item k+2 first: the atomic's round trip runs under the poll / DMA issue below
             unsigned nx = 0xffffffffu;                                    // (never a counter value)
-            if (leader && it1 >= 0 && lane == 0)
-                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(nx) : "v"(work), "v"(1u) : "memory");
+            const bool fetch = leader && it1 >= 0;
+            if (fetch && lane == 0)
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(nx) : "v"(qown), "v"(1u) : "memory");
             if (it1 >= 0) {
                 const int l1 = __builtin_amdgcn_readfirstlane(s1[1]), n1 = __builtin_amdgcn_readfirstlane(s1[2]);
                 const int ty1 = __builtin_amdgcn_readfirstlane(s1[3]), tx1 = __builtin_amdgcn_readfirstlane(s1[4]);
@@ -251,14 +299,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 int* s2 = ctl + 8 * ((k + 2) % 3);
                 int it2 = -1, l2 = 0, n2 = 0, ty2 = 0, tx2 = 0;
                 bool ok2 = false;
-                if (it1 >= 0) {
+                if (fetch) {
                     // exactly NPIECE_W vector-memory instructions of this wave are younger than the atomic (vmcnt counts in issue order)
                     asm volatile("s_waitcnt vmcnt(11)" : "+v"(nx) :: "memory");
                     static_assert(NPIECE_W == 11, "the counted wait above");
                     if (__builtin_amdgcn_readfirstlane((int)nx) == -1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx) :: "memory");   // (belt and braces)
-                    it2 = __builtin_amdgcn_readfirstlane((int)nx);
-                    if (it2 >= total) it2 = -1;
-                    else {
+                    it2 = chain_item((unsigned)__builtin_amdgcn_readfirstlane((int)nx), own, R, tiles, ntx, ka.nlayers);
+                    if (it2 >= 0) {
                         l2 = it2 / tiles; const int r = it2 - l2 * tiles; n2 = r / per; const int r2 = r - n2 * per; ty2 = r2 / ntx; tx2 = r2 - ty2 * ntx;
                         // its dependencies, looked at now, used a barrier later (the result returns behind this wave's DMA pieces,
                         // i.e. under the wait for the tile that is needed anyway)
@@ -529,7 +576,7 @@ extern "C" int vsr_debug_chain_timeouts(unsigned* host_out) {
 }
 
 size_t vsr_chain_sync_bytes(int nlayers, int N, int H, int W) {
-    return 256 + (size_t)nlayers * N * cdiv(H, PTH) * cdiv(W, PTW) * 16;
+    return 1024 + (size_t)nlayers * N * cdiv(H, PTH) * cdiv(W, PTW) * 16;
 }
 
 // a.sync: vsr_chain_sync_bytes() of device memory owned by this launch until it has finished (zeroed here, on the stream)

@@ -571,8 +571,8 @@ int get_helper(Helper** out) {
 bool single_stream() { return vsr_env().single_stream; }
 struct Fork {   // RAII: the join is enqueued on every exit path
     hipStream_t main; Helper* h; bool active = false;
-    int begin() {
-        if (single_stream()) return VSR_OK;
+    int begin(bool fork = true) {
+        if (single_stream() || !fork) return VSR_OK;
         CK(get_helper(&h));
         HIP_CHECK_RET(hipEventRecord(h->fork, main));
         HIP_CHECK_RET(hipStreamWaitEvent(h->s, h->fork, 0));
@@ -615,7 +615,9 @@ int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float
     if (t > 1) CK(spynet_run(c, p.spy, lrs, prm[ix.spy_mean()], prm[ix.spy_std()], n, t, 0, (float*)c.at(p.flows)));
     {
         Fork f{st, nullptr};
-        CK(f.begin());
+        // (chain launches spin on each other's tiles: two of them side by side could each hold the CUs the other's unstarted
+        // workgroups need -- conv3x3_chain.hip, "Work distribution" -- so with the chains on, both directions share the caller's stream)
+        CK(f.begin(!chain_on(p)));
         const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
         CK(forward_chain(c0, p, 0, lrs));
         CK(forward_chain(c1, p, 1, lrs));
@@ -907,7 +909,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st));
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
-    CK(f.begin());
+    CK(f.begin(!chain_on(p)));
     const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
     CK(backward_chain(c0, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
@@ -932,7 +934,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
 // ================================ C ABI =========================================================
 extern "C" {
 
-int vsr_abi_version(void) { return 3; }
+int vsr_abi_version(void) { return 4; }
 
 const char* vsr_status_string(int s) {
     switch (s) {
