@@ -46,7 +46,7 @@ DTYPES = ["fp32", "bf16"]
 def test_library_loaded_and_abi():
     import vsrlab_amd
     lib = vsrlab_amd._lib.load()
-    assert lib.vsr_abi_version() == 3
+    assert lib.vsr_abi_version() == 4
     _gpu()
 
 
