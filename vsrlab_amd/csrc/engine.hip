@@ -216,7 +216,7 @@ struct Plan {
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
         }
         // the trunk chains' work / row counters (conv3x3_chain.hip), one block per direction (= per stream)
-        for (int dir = 0; dir < 2; ++dir) chain_sync[dir] = (bwd && !diet && dtype == VSR_BF16) ? b.take(vsr_chain_sync_bytes(VSR_CHAIN_MAX_LAYERS, n, h, w)) : 0;
+        for (int dir = 0; dir < 2; ++dir) chain_sync[dir] = (bwd && dtype == VSR_BF16) ? b.take(vsr_chain_sync_bytes(VSR_CHAIN_MAX_LAYERS, n, h, w)) : 0;
         // appended last, so that every other offset is the same in modes 1 and 2
         dflows = 0;
         if (flowgrad && t > 1) {
@@ -810,8 +810,8 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
     } else {
         CK(vsr_launch_add_cast(c.dtype, dtop, nullptr, c.at(p.dxoff(dir, i, rb)), n, h, w, C, c.st));
     }
-    const bool chain = chain_on(p);
-    if (chain) CK(trunk_chain_backward(c, p, dir, i));
+    const bool chain = chain_on(p) && !p.diet;            // diet: the activation gradients live in a two-block ring, the frame's weight
+    if (chain) CK(trunk_chain_backward(c, p, dir, i));     // gradients are launched block by block behind them (the forward chain stays)
     for (int b = chain ? 0 : rb - 1; b >= 0; --b) {
         const void* dxn = c.at(p.dxoff(dir, i, b + 1));
         // dA = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b)
@@ -909,7 +909,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st));
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
-    CK(f.begin(!chain_on(p)));
+    CK(f.begin(!(chain_on(p) && !p.diet)));          // (diet: no chain launches in the backward, the two directions keep their two streams)
     const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
     CK(backward_chain(c0, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
