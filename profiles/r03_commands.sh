@@ -2,6 +2,7 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3final
 mkdir -p $O
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -1 $O/bench_default.json | cut -c1-600 &&
+VSRLAB_AMD_CHAIN=0 timeout -k 10 250 python bench.py --no-cpu-baseline > $O/bench_chain_off.json 2> $O/bench_chain_off.err &&
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace2s -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/trace2s.log 2>&1 &&
 VSRLAB_AMD_SINGLE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1s -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/trace1s.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o rl -- python3 bench.py --roofline-only > $O/pmc_fetch.log 2>&1 &&
