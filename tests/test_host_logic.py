@@ -406,3 +406,41 @@ def test_drop_path_is_the_references_stochastic_depth():
     assert isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob == 0.25
     grp = TMSAG(dim=24, input_resolution=(2, 8, 8), depth=2, num_heads=2, window_size=[2, 8, 8], drop_path=[0.0, 0.3])
     assert isinstance(grp.blocks[0].drop_path, torch.nn.Identity) and grp.blocks[1].drop_path.drop_prob == 0.3
+
+
+def test_chain_work_distribution_hands_out_every_tile_of_every_layer_once():
+    """conv3x3_chain.hip, "Work distribution": the position -> (layer, tile) map the chain kernel's workgroups pull their work from,
+    evaluated on the host (vsr_debug_chain_item).  For R = 8 regions and R = 1, tile counts from 1 to the 540p frame's 2040
+    (also fewer tiles than regions, and a batch of two): every item of every layer exactly once over all regions, -1 behind the
+    last layer, and within a region the layer never goes back (the progress argument of the kernel rests on these two)."""
+    from vsrlab_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    f = lib.vsr_debug_chain_item
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for (tiles, ntx, nlayers) in [(1, 1, 3), (5, 2, 4), (8, 2, 2), (9, 3, 3), (16, 2, 5), (61, 30, 2), (275, 11, 3), (2040, 30, 2), (4080, 30, 2)]:
+        for R in (1, 8):
+            seen = set()
+            for own in range(R):
+                last_layer, P = 0, 0
+                while True:
+                    it = f(P, own, R, tiles, ntx, nlayers)
+                    if it < 0:
+                        break
+                    assert 0 <= it < tiles * nlayers and it not in seen, (tiles, ntx, nlayers, R, own, P, it)
+                    seen.add(it)
+                    assert it // tiles >= last_layer, (tiles, R, own, P)
+                    last_layer = it // tiles
+                    P += 1
+                assert all(f(P + k, own, R, tiles, ntx, nlayers) < 0 for k in range(1, 40))
+            assert len(seen) == tiles * nlayers, (tiles, ntx, nlayers, R, len(seen))
+
+
+def test_chain_abi_rejects_bad_arguments_without_touching_the_gpu():
+    from vsrlab_amd import _lib
+    lib = _lib.load()
+    assert lib.vsr_conv3x3_c64_chain_sync_bytes(0, 1, 8, 8) == 0 and lib.vsr_conv3x3_c64_chain_sync_bytes(65, 1, 8, 8) == 0
+    assert lib.vsr_conv3x3_c64_chain_sync_bytes(60, 1, 540, 960) == 1024 + 60 * 2040 * 16
+    assert lib.vsr_conv3x3_c64_chain_fwd(None, None, None, 2, 1, 8, 8, None, None) == -1
+    # misaligned operands: refused (offsets are in units of 256 bytes from one base), before any launch
+    assert lib.vsr_conv3x3_c64_chain_fwd(0x10000100, 0x20000000, 0x30000010, 2, 1, 8, 8, 0x40000000, None) == -2

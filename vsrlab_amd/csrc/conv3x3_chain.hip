@@ -131,12 +131,12 @@ __device__ __forceinline__ bool halo_wait(const gu32* flg, int ty, int tx, int n
 // long as every region has a workgroup that is or becomes resident, i.e. as long as no other kernel that waits for THIS one
 // holds its CUs: the engine therefore runs its chain launches on one stream.  (R = 1, one counter = one global order, when the
 // grid is not a multiple of 8 workgroups.)
-__device__ __forceinline__ int chain_rlo(int r, int tiles, int R) { return (int)((long long)r * tiles / R); }
+__host__ __device__ __forceinline__ int chain_rlo(int r, int tiles, int R) { return (int)((long long)r * tiles / R); }
 // The p-th tile handed out of a region of `sz` tiles: chunks of `ntx` consecutive tiles (about one tile row), taken MIDDLE-OUT
 // (m, m+1, m-1, m+2, ...).  In the next layer a chunk needs its neighbour chunks of this layer (the 3x3 halo): with the same
 // order in every layer those were handed out a whole layer earlier, also across region borders, whose chunks come last --
 // top-to-bottom, the first chunk of every region would wait for the previous region's LAST chunk of the layer before.
-__device__ __forceinline__ int chain_region_tile(int p, int sz, int ntx) {
+__host__ __device__ __forceinline__ int chain_region_tile(int p, int sz, int ntx) {
     const int nch = (sz + ntx - 1) / ntx, m = nch >> 1, D = m, U = nch - 1 - m;
     const int lim = 2 * (U < D ? U : D);
     for (int sq = 0; sq < nch; ++sq) {
@@ -151,7 +151,7 @@ __device__ __forceinline__ int chain_region_tile(int p, int sz, int ntx) {
     return sz - 1;      // (not reached for p < sz)
 }
 // position P of region `own` -> item (layer * tiles + tile), or -1 behind the last layer
-__device__ __forceinline__ int chain_item(unsigned P, int own, int R, int tiles, int ntx, int nlayers) {
+__host__ __device__ __forceinline__ int chain_item(unsigned P, int own, int R, int tiles, int ntx, int nlayers) {
     const int lo = chain_rlo(own, tiles, R), sz = chain_rlo(own + 1, tiles, R) - lo;
     if (sz <= 0) return -1;
     const int l = (int)(P / (unsigned)sz);
@@ -569,6 +569,12 @@ extern "C" int vsr_debug_read_clk_chain(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clk_chain), sizeof(unsigned long long) * 256 * 2) == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 #endif
+
+// The work-distribution map of the chain kernel on the host (tests: every (layer, tile) must be handed out exactly once, and a
+// region's positions must never go back a layer): position P of region `own` of R -> item = layer * tiles + tile, or -1.
+extern "C" int vsr_debug_chain_item(unsigned P, int own, int R, int tiles, int ntx, int nlayers) {
+    return chain_item(P, own, R, tiles, ntx, nlayers);
+}
 
 // dependency waits that were given up (1 s each) since the library was loaded: anything but 0 voids the results of that run
 extern "C" int vsr_debug_chain_timeouts(unsigned* host_out) {
