@@ -53,7 +53,9 @@ constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11;
 
 // Diagnostic build only (make ABL=<bits> ABLSRC=conv3x3_chain; results may be WRONG, only the run time is read): bit 0: plain
 // instead of write-through stores; bit 1: plain instead of sc1 loads; bit 2: no dependency waits (every item counts as ready);
-// bit 3: no publishes; bit 4: no wait for the previous tile's stores at the top of an epilogue without operands.
+// bit 3: no publishes; bit 4: no wait for the previous tile's stores at the top of an epilogue without operands; bit 5: no fragment
+// reads after step 0 (bare MFMA loop); bit 6: the producers issue only their first tile (no DMA); bit 7: no output stores.  On the
+// back-to-back leg the kernel's time is its energy, so these price the energy of LDS reads / DMA / stores.
 #ifdef VSR_ABL
 #define CABL(bit) ((VSR_ABL >> (bit)) & 1)
 __device__ unsigned long long g_clk_chain[256 * 2];      // [workgroup][cycles, 100 MHz ticks] of the last chain launch
@@ -62,6 +64,12 @@ __device__ unsigned long long g_clk_chain[256 * 2];      // [workgroup][cycles, 
 #endif
 #if CABL(0)
 #define CH_SC1_ST ""
+#elif CABL(8)
+#define CH_SC1_ST " sc1 nt"
+#elif CABL(9)
+#define CH_SC1_ST " nt"
+#elif CABL(10)
+#define CH_SC1_ST " sc0 sc1"
 #else
 #define CH_SC1_ST " sc1"
 #endif
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                     if (leader && lane == 0) s1[5] = 1;   // tells the MFMA waves that their deferred publish cannot be what we wait for
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                issue(l1, n1, ty1, tx1, (k + 1) & 1);
+                if (!CABL(6)) issue(l1, n1, ty1, tx1, (k + 1) & 1);
             }
             if (leader) {
                 int* s2 = ctl + 8 * ((k + 2) % 3);
@@ -431,8 +439,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 bf16x8_t fa[2][4], fb[2][4];
                 const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);
 #define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
-#define CV_LOADA(tap_, kk_, slot, mb) DSR(fa[slot][mb], (tap_ < 6 ? a_lo[kk_] : a_hi[kk_]), (tap_ < 6 ? tap_ : tap_ - 6) * 8192 + (mb) * 2048);
-#define CV_LOADB(ky_, kx_, kk_, slot, nb) DSR(fb[slot][nb], bb, (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
+#define CV_LOADA(tap_, kk_, slot, mb) if (!(CABL(5) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (tap_ < 6 ? a_lo[kk_] : a_hi[kk_]), (tap_ < 6 ? tap_ : tap_ - 6) * 8192 + (mb) * 2048);
+#define CV_LOADB(ky_, kx_, kk_, slot, nb) if (!(CABL(5) && ky_ + kx_ + kk_ > 0)) DSR(fb[slot][nb], bb, (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
 #define CV_LOAD(s, slot)                                                                                               \
                 {                                                                                                      \
                     constexpr int tap_ = (s) / 2, kk_ = (s) % 2, ky_ = tap_ / 3, kx_ = tap_ % 3;                       \
@@ -526,7 +534,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                                 // write-through: the next layer's tiles may be loaded on another XCD
                                 // (asm: `s_nop 1` behind a 16-byte store, or hipcc's next instruction may overwrite the data registers before
                                 // the store has read them; `s_nop 4` in front of the first user of the freshly added base; 5.7 items 1, 2)
-                                if (kq == 0) {
+                                if (CABL(7)) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+                                else if (kq == 0) {
                                     if (nb == 0 || !decltype(FULL)::value) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" CH_SC1_ST "\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
                                     else asm volatile("global_store_dwordx4 %0, %1, %2" CH_SC1_ST "\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
                                 } else asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048" CH_SC1_ST "\n\ts_nop 1" :: "v"(lo), "v"(o), "s"(db) : "memory");
