@@ -1011,6 +1011,45 @@ def test_conv3x3_c64_chain_abi_matches_the_per_layer_calls(shape, blocks):
     assert _chain_timeouts() == t0
 
 
+def test_chain_hand_off_under_uneven_load_from_a_second_stream():
+    """The chain's workgroups hand tiles to each other inside the launch; its progress argument allows any share of the grid to be
+    resident.  Here a second stream keeps the chip busy with unrelated work of uneven length (large and small GEMMs, element-wise
+    passes) while 24-layer chains run on the first, so that chain workgroups start late, on whatever CUs are free, next to
+    kernels that evict their L2 lines: every word of every intermediate image must still equal the quiet run's, and no
+    dependency wait may time out."""
+    dev = _gpu()
+    from vsrlab_amd import functional as VF
+    n, h, w, L = 1, 216, 384, 24
+    ws = [(rand(900 + l, 64, 64, 3, 3, lo=-1, hi=1) / 24.0).to(dev) for l in range(L)]
+    bs = [rand(950 + l, 64, lo=-0.1, hi=0.1).to(dev) for l in range(L)]
+    x = VF.to_pixel_major(rand(899, n, 64, h, w, lo=-1, hi=1).to(dev), VF.DT_BF16)
+    t0 = _chain_timeouts()
+    ch = VF.ResidualChainC64(ws, bs, n, h, w, dev)
+    ch(x)
+    torch.cuda.synchronize()
+    quiet = ch.images.clone()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(256, 256, device=dev)
+    big = torch.randn(64 * 1024 * 1024, device=dev)
+    for rep in range(6):
+        ch.images[ch.img_elems:].zero_()                       # every layer's output must be produced again
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for k in range(12):
+                if (k + rep) % 3 == 0:
+                    a = (a @ a).clamp_(-1, 1)
+                elif (k + rep) % 3 == 1:
+                    b = torch.tanh(b @ b)
+                else:
+                    big.mul_(1.0001)
+        for _ in range(2):
+            ch.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(ch.images, quiet), rep
+    assert _chain_timeouts() == t0
+
+
 def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
     is process-wide, so they run in a child, like the pipelined-conv A/B above."""
