@@ -383,6 +383,11 @@ def main():
                        "arena": args.arena, "train_flow": bool(args.train_flow), "peak_hbm_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
             "loss": round(loss_val, 6), "tree": tree_id(),
         }
+        # the trunk chains hand tiles between workgroups inside a launch; a wait that timed out would have left wrong results behind
+        from vsrlab_amd import functional as _VF
+        out["config"]["trunk_chains"] = os.environ.get("VSRLAB_AMD_CHAIN", "1") != "0" and args.dtype == "bf16"
+        if _VF.chain_timeouts() != 0:
+            raise RuntimeError(f"vsrlab_amd: {_VF.chain_timeouts()} chain dependency waits timed out: the run is void")
         bpf = algorithmic_bytes_per_frame(h, w, t, args.res_blocks, 2 if args.dtype == "bf16" else 4)
         fpf = flops_per_frame(h, w, t, args.res_blocks)
         out["path_roofline"] = {"algorithmic_GB_per_frame": round(bpf / 1e9, 3), "TFLOP_per_frame": round(fpf / 1e12, 3),

@@ -947,12 +947,8 @@ def test_diet_arena_matches_the_full_arena(dtype):
 
 
 def _chain_timeouts():
-    import ctypes
-    from vsrlab_amd import _lib
-    out = ctypes.c_uint(0)
-    lib = _lib.load()
-    assert lib.vsr_debug_chain_timeouts(ctypes.byref(out)) == 0
-    return out.value
+    from vsrlab_amd import functional as VF
+    return VF.chain_timeouts()
 
 
 def test_trunk_chain_launch_is_bit_identical_to_one_launch_per_layer():

@@ -162,6 +162,15 @@ def conv3x3_c64(x_pm: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return y
 
 
+def chain_timeouts() -> int:
+    """Dependency waits the trunk-chain kernel (csrc/conv3x3_chain.hip) has given up since the library was loaded (1 s each).
+    Anything but 0 means some launch ran on unfinished inputs: its results are void.  Synchronises the device."""
+    import ctypes
+    out = ctypes.c_uint(0)
+    _lib.check(_lib.load().vsr_debug_chain_timeouts(ctypes.byref(out)), "debug_chain_timeouts")
+    return int(out.value)
+
+
 class ResidualChainC64:
     """The body of ResidualBlock.res_block (conv.py:85-92, 99-103) as ONE launch (vsr_conv3x3_c64_chain_fwd): `blocks`
     ResidualConv blocks on a blocked 64-channel bf16 image, every intermediate kept.  Holds one allocation with the
