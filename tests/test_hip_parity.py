@@ -1046,6 +1046,29 @@ def test_chain_hand_off_under_uneven_load_from_a_second_stream():
     assert _chain_timeouts() == t0
 
 
+@pytest.mark.parametrize("shape", [(2, 21, 70), (1, 135, 250)])
+def test_weights_in_registers_experiment_is_bit_identical(shape):
+    """conv3x3_wreg.hip (VSRLAB_AMD_WREG=1, read per launch): four 512-register waves with the nine taps' A fragments in
+    registers, B fragments from LDS only, the tile DMA issued by the MFMA waves into three buffers -- the two trunk epilogues
+    against conv3x3_persist on the same operands, bit for bit (ragged batch of two; more tiles than fit three buffers per
+    workgroup)."""
+    dev = _gpu()
+    from vsrlab_amd import functional as VF
+    n, h, w = shape
+    x = VF.to_pixel_major(rand(1200, n, 64, h, w, lo=-1, hi=1).to(dev), VF.DT_BF16)
+    r = VF.to_pixel_major(rand(1201, n, 64, h, w, lo=-1, hi=1).to(dev), VF.DT_BF16)
+    wt = (rand(1202, 64, 64, 3, 3, lo=-1, hi=1) / 24.0).to(dev)
+    b = rand(1203, 64, lo=-0.1, hi=0.1).to(dev)
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["VSRLAB_AMD_WREG"] = mode
+        try:
+            out[mode] = (VF.from_pixel_major(VF.conv3x3_c64(x, wt, b, act=1)), VF.from_pixel_major(VF.conv3x3_c64(x, wt, b, act=0, res_pm=r)))
+        finally:
+            os.environ.pop("VSRLAB_AMD_WREG", None)
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+
+
 def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
     is process-wide, so they run in a child, like the pipelined-conv A/B above."""

@@ -55,7 +55,8 @@ constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11;
 // instead of write-through stores; bit 1: plain instead of sc1 loads; bit 2: no dependency waits (every item counts as ready);
 // bit 3: no publishes; bit 4: no wait for the previous tile's stores at the top of an epilogue without operands; bit 5: no fragment
 // reads after step 0 (bare MFMA loop); bit 6: the producers issue only their first tile (no DMA); bit 7: no output stores; bit 11: every fragment read
-// of a tile re-reads the first K step's addresses (the LDS reads stay, the operands stop changing); bit 12: epilogue = convert + store.  On the
+// of a tile re-reads the first K step's addresses (the LDS reads stay, the operands stop changing); bit 12: epilogue = convert + store; bit 13 / 14: no A (weight) / no B (pixel)
+// fragment reads after the first K step (what weights held in registers would save).  On the
 // back-to-back leg the kernel's time is its energy, so these price the energy of LDS reads / DMA / stores.
 #ifdef VSR_ABL
 #define CABL(bit) ((VSR_ABL >> (bit)) & 1)
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 bf16x8_t fa[2][4], fb[2][4];
                 const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);
 #define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
-#define CV_LOADA(tap_, kk_, slot, mb) if (!(CABL(5) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (CABL(11) ? a_lo[0] : (tap_ < 6 ? a_lo[kk_] : a_hi[kk_])), (CABL(11) ? 0 : (tap_ < 6 ? tap_ : tap_ - 6) * 8192) + (mb) * 2048);
-#define CV_LOADB(ky_, kx_, kk_, slot, nb) if (!(CABL(5) && ky_ + kx_ + kk_ > 0)) DSR(fb[slot][nb], bb, CABL(11) ? (((nb) >> 1)) * (PTWH * 128) + (((nb) & 1) * 16) * 16 : (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
+#define CV_LOADA(tap_, kk_, slot, mb) if (!((CABL(5) || CABL(13)) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (CABL(11) ? a_lo[0] : (tap_ < 6 ? a_lo[kk_] : a_hi[kk_])), (CABL(11) ? 0 : (tap_ < 6 ? tap_ : tap_ - 6) * 8192) + (mb) * 2048);
+#define CV_LOADB(ky_, kx_, kk_, slot, nb) if (!((CABL(5) || CABL(14)) && ky_ + kx_ + kk_ > 0)) DSR(fb[slot][nb], bb, CABL(11) ? (((nb) >> 1)) * (PTWH * 128) + (((nb) & 1) * 16) * 16 : (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
 #define CV_LOAD(s, slot)                                                                                               \
                 {                                                                                                      \
                     constexpr int tap_ = (s) / 2, kk_ = (s) % 2, ky_ = tap_ / 3, kx_ = tap_ % 3;                       \
