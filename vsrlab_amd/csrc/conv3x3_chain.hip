@@ -56,7 +56,8 @@ constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11;
 // bit 3: no publishes; bit 4: no wait for the previous tile's stores at the top of an epilogue without operands; bit 5: no fragment
 // reads after step 0 (bare MFMA loop); bit 6: the producers issue only their first tile (no DMA); bit 7: no output stores; bit 11: every fragment read
 // of a tile re-reads the first K step's addresses (the LDS reads stay, the operands stop changing); bit 12: epilogue = convert + store; bit 13 / 14: no A (weight) / no B (pixel)
-// fragment reads after the first K step (what weights held in registers would save).  On the
+// fragment reads after the first K step (what weights held in registers would save); bit 15: the weight image in LDS in MFMA-fragment
+// order (every A read = 1 KiB contiguous) instead of [cout row][8 swizzled chunks] -- same results, an energy experiment.  On the
 // back-to-back leg the kernel's time is its energy, so these price the energy of LDS reads / DMA / stores.
 #ifdef VSR_ABL
 #define CABL(bit) ((VSR_ABL >> (bit)) & 1)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
     _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
         const int idx = tid + i * 256;                                                                                   \
         const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
-        *reinterpret_cast<u32x4_t*>(lds_w + tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16) = wv[i];                     \
+        *reinterpret_cast<u32x4_t*>(lds_w + (CABL(15) ? ((((tap * 2 + (c >> 2)) * 4 + (r >> 4)) * 64 + (c & 3) * 16 + (r & 15)) * 16) : tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16)) = wv[i]; \
     }
     constexpr int WCH = 9 * 64 * 8 / 256;
 
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
         unsigned a_lo[2], a_hi[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            a_lo[kk] = (unsigned)((l15 * 8 + ((4 * kk + q) ^ ((l15 >> 1) & 7))) * 16);
+            a_lo[kk] = CABL(15) ? (unsigned)((q * 16 + l15) * 16 + kk * 4096) : (unsigned)((l15 * 8 + ((4 * kk + q) ^ ((l15 >> 1) & 7))) * 16);
             a_hi[kk] = a_lo[kk] + 6 * 8192;
         }
         const int b_lane = w4 * 2 * (PTWH * 128) + q * (PTWH * 16) + pxl * 16;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 bf16x8_t fa[2][4], fb[2][4];
                 const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);
 #define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
-#define CV_LOADA(tap_, kk_, slot, mb) if (!((CABL(5) || CABL(13)) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (CABL(11) ? a_lo[0] : (tap_ < 6 ? a_lo[kk_] : a_hi[kk_])), (CABL(11) ? 0 : (tap_ < 6 ? tap_ : tap_ - 6) * 8192) + (mb) * 2048);
+#define CV_LOADA(tap_, kk_, slot, mb) if (!((CABL(5) || CABL(13)) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (CABL(11) ? a_lo[0] : (tap_ < 6 ? a_lo[kk_] : a_hi[kk_])), (CABL(11) ? 0 : (tap_ < 6 ? tap_ : tap_ - 6) * 8192) + (mb) * (CABL(15) ? 1024 : 2048));
 #define CV_LOADB(ky_, kx_, kk_, slot, nb) if (!((CABL(5) || CABL(14)) && ky_ + kx_ + kk_ > 0)) DSR(fb[slot][nb], bb, CABL(11) ? (((nb) >> 1)) * (PTWH * 128) + (((nb) & 1) * 16) * 16 : (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
 #define CV_LOAD(s, slot)                                                                                               \
                 {                                                                                                      \
