@@ -212,6 +212,43 @@ def per_layer_kernel_roofline(dev, h, w, iters=48, nsets=8):
     return out
 
 
+def chains_in_step_live(model, crit, lrs, hr, opt, args):
+    """The dominant kernel INSIDE a step, live: one more forward + backward of the same clip behind the timed region (no collective, no
+    optimizer step; rank 0 only) with every trunk-chain launch of the engine bracketed by a pair of HIP events on its stream
+    (vsr_debug_chain_timing_begin / _read, csrc/conv3x3_chain.hip).  Algorithmic bytes per launch as in dominant_kernel_roofline plus the
+    sign bits (8 bytes per pixel and ReLU layer); call-weighted over the step's launches."""
+    import ctypes
+    from vsrlab_amd import _lib
+    lib = _lib.load()
+    if not hasattr(lib, "vsr_debug_chain_timing_begin") or os.environ.get("VSRLAB_AMD_CHAIN", "1") == "0":
+        return None
+    if lib.vsr_debug_chain_timing_begin() != 0:
+        return None
+    sr = model(lrs)
+    crit(sr, hr).backward()
+    torch.cuda.synchronize()
+    opt.zero_grad(set_to_none=(args.optimizer == "torch"))
+    M = 64
+    us, layers, var, px = (ctypes.c_float * M)(), (ctypes.c_int * M)(), (ctypes.c_int * M)(), (ctypes.c_longlong * M)()
+    n = lib.vsr_debug_chain_timing_read(us, layers, var, px, M)
+    if n <= 0:
+        return None
+    tot_b = tot_us = 0.0
+    per = {"forward": [0.0, 0], "backward": [0.0, 0]}
+    for i in range(n):
+        P, L = float(px[i]), layers[i]
+        skip, even = L // 2, L - L // 2
+        tot_b += even * (2 * 64 * P * 2 + 8 * P) + skip * 3 * 64 * P * 2
+        tot_us += us[i]
+        k = "forward" if var[i] == 0 else "backward"
+        per[k][0] += us[i]
+        per[k][1] += L
+    gbs = tot_b / (tot_us * 1e-6) / 1e9
+    return {"what": "every conv3x3_c64_chain_kernel launch of one forward + backward behind the timed region, HIP events on its stream",
+            "launches": n, "us_per_layer": {k: round(v[0] / v[1], 2) for k, v in per.items() if v[1]},
+            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def host_cores():
     """CPU share of this job: the affinity mask, capped at 16 (a 1-GPU box's share; os.cpu_count()
     reports the whole host and oversubscribing it makes oneDNN crawl)."""
@@ -394,9 +431,12 @@ def main():
                                 "achieved_GBs_per_gpu": round(bpf * frames_per_s / world / 1e9, 1),
                                 "hbm_frac": round(bpf * frames_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                                 "achieved_TFLOPs_per_gpu": round(fpf * frames_per_s / world / 1e12, 1)}
+        live = chains_in_step_live(model, crit, lrs, hr, opt, args) if args.dtype == "bf16" else None
         if args.dtype == "bf16":                             # the dominant kernel's leg: rank 0's GPU, after the timed region, at every N
             out["roofline"] = dominant_kernel_roofline(dev, h, w)
             log(f"dominant kernel: {out['roofline']['avg_us']} us")
+            if live is not None:
+                out["roofline"]["in_step_live"] = live
         if world == 1 and not args.no_cpu_baseline:          # the CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(h, w)
         print(json.dumps(out), flush=True)

@@ -600,6 +600,14 @@ size_t vsr_chain_sync_bytes(int nlayers, int N, int H, int W) {
     return 1024 + (size_t)nlayers * N * cdiv(H, PTH) * cdiv(W, PTW) * 16;
 }
 
+struct ChainTiming {
+    static constexpr int MAX = 64;
+    bool on = false; int n = 0;
+    hipEvent_t ev[2 * MAX] = {};
+    int layers[MAX], variant[MAX]; long long pixels[MAX];
+};
+static ChainTiming& chain_timing() { static ChainTiming t; return t; }      // process-wide: autograd runs the backward on a thread of its own (a diagnostic: calls are not concurrent)
+
 // a.sync: vsr_chain_sync_bytes() of device memory owned by this launch until it has finished (zeroed here, on the stream)
 int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st) {
     if (!a.base || !a.sync || a.nlayers < 1 || a.nlayers > VSR_CHAIN_MAX_LAYERS || a.N < 1 || a.H < 1 || a.W < 1) return VSR_ERR_BADARG;
@@ -621,7 +629,38 @@ int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st) {
     int gx = num_cus / (a.cu_div > 1 ? a.cu_div : 1);
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = (int)tiles;
+    ChainTiming& T = chain_timing();
+    const int slot = T.on && T.n < ChainTiming::MAX ? T.n : -1;
+    if (slot >= 0) HIP_CHECK_RET(hipEventRecord(T.ev[2 * slot], st));
     hipLaunchKernelGGL(kern, dim3(gx), dim3(PNT), P_LDS, st, a);
     HIP_CHECK_RET(hipGetLastError());
+    if (slot >= 0) {
+        HIP_CHECK_RET(hipEventRecord(T.ev[2 * slot + 1], st));
+        T.layers[slot] = a.nlayers; T.variant[slot] = even; T.pixels[slot] = (long long)a.N * a.H * a.W;
+        T.n = slot + 1;
+    }
     return VSR_OK;
+}
+
+// Timing of the chain launches of the engine, live: between begin and read every chain launch of the process is bracketed by a
+// pair of HIP events on the stream it is launched on (bench.py: one extra, un-timed step behind the timed region).
+extern "C" int vsr_debug_chain_timing_begin(void) {
+    ChainTiming& T = chain_timing();
+    if (!T.ev[0])
+        for (int i = 0; i < 2 * ChainTiming::MAX; ++i) HIP_CHECK_RET(hipEventCreate(&T.ev[i]));
+    T.n = 0; T.on = true;
+    return VSR_OK;
+}
+// us[i], layers[i], variant[i] (CHAIN_RELU forward / CHAIN_MASK backward), pixels[i] of launch i; returns the number of launches
+// (the caller has synchronised the stream) or a negative status
+extern "C" int vsr_debug_chain_timing_read(float* us, int* layers, int* variant, long long* pixels, int max) {
+    ChainTiming& T = chain_timing();
+    T.on = false;
+    const int n = T.n < max ? T.n : max;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_CHECK_RET(hipEventElapsedTime(&ms, T.ev[2 * i], T.ev[2 * i + 1]));
+        us[i] = ms * 1e3f; layers[i] = T.layers[i]; variant[i] = T.variant[i]; pixels[i] = T.pixels[i];
+    }
+    return n;
 }
