@@ -1048,7 +1048,7 @@ def test_chain_hand_off_under_uneven_load_from_a_second_stream():
 
 @pytest.mark.parametrize("shape", [(2, 21, 70), (1, 135, 250)])
 def test_weights_in_registers_experiment_is_bit_identical(shape):
-    """conv3x3_wreg.hip (VSRLAB_AMD_WREG=1, read per launch): four 512-register waves with the nine taps' A fragments in
+    """conv3x3_wreg.hip (VSRLAB_AMD_WREG=1 / vsr_debug_set_wreg): four 512-register waves with the nine taps' A fragments in
     registers, B fragments from LDS only, the tile DMA issued by the MFMA waves into three buffers -- the two trunk epilogues
     against conv3x3_persist on the same operands, bit for bit (ragged batch of two; more tiles than fit three buffers per
     workgroup)."""
@@ -1060,12 +1060,14 @@ def test_weights_in_registers_experiment_is_bit_identical(shape):
     wt = (rand(1202, 64, 64, 3, 3, lo=-1, hi=1) / 24.0).to(dev)
     b = rand(1203, 64, lo=-0.1, hi=0.1).to(dev)
     out = {}
+    from vsrlab_amd import _lib
+    lib = _lib.load()
     for mode in ("0", "1"):
-        os.environ["VSRLAB_AMD_WREG"] = mode
+        lib.vsr_debug_set_wreg(int(mode))
         try:
             out[mode] = (VF.from_pixel_major(VF.conv3x3_c64(x, wt, b, act=1)), VF.from_pixel_major(VF.conv3x3_c64(x, wt, b, act=0, res_pm=r)))
         finally:
-            os.environ.pop("VSRLAB_AMD_WREG", None)
+            lib.vsr_debug_set_wreg(0)
     assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
 
 

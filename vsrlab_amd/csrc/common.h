@@ -184,6 +184,7 @@ struct VsrEnvSwitches {
     bool generic_conv, generic_wgrad, attn_generic, single_stream;
     int wide2_max_wg;
     bool conv_pipe;           // VSRLAB_AMD_CONV_PIPE (default 0: r03 measured 138.8 vs 141.3 ms/step off vs on; on wins only where the residual loads stall): pipelined tile loop of the bias+skip persistent conv (A/B)
+    bool wreg;                // VSRLAB_AMD_WREG: the weights-in-registers experiment (conv3x3_wreg.hip) for the launches it supports; off by default
     int chain_share;          // VSRLAB_AMD_CHAIN_SHARE: CU share divisor of the two propagation chains' persistent launches (A/B; default 1: r03 measured 136.9 vs 137.0 ms/step for 1 vs 2)
 };
 static inline const VsrEnvSwitches& vsr_env() {
@@ -198,6 +199,7 @@ static inline const VsrEnvSwitches& vsr_env() {
         v.wide2_max_wg = e ? atoi(e) : 0;
         e = getenv("VSRLAB_AMD_CONV_PIPE");
         v.conv_pipe = e && e[0] == '1';
+        v.wreg = on("VSRLAB_AMD_WREG");
         e = getenv("VSRLAB_AMD_CHAIN_SHARE");
         v.chain_share = e ? atoi(e) : 1;
         if (v.chain_share < 1 || v.single_stream) v.chain_share = 1;

@@ -775,11 +775,12 @@ extern "C" int vsr_debug_read_stamps(unsigned long long* host_out) {
 // step, 64 output channels, blocked pixel-major destination).  Returns VSR_ERR_UNSUPPORTED for an epilogue
 // combination that has no instantiation; the caller then uses the generic kernel.
 int vsr_launch_conv3x3_c64_wreg(const ConvArgs& a, int num_cus, hipStream_t st);      // conv3x3_wreg.hip (experiment)
+static int g_wreg_on = -1;        // -1: not decided yet (then VSRLAB_AMD_WREG through vsr_env()), 0 / 1
+extern "C" void vsr_debug_set_wreg(int on) { __atomic_store_n(&g_wreg_on, on ? 1 : 0, __ATOMIC_RELAXED); }
 int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
-    {   // VSRLAB_AMD_WREG=1 (read per launch: an A/B switch): the weights-in-registers experiment for the launches it supports
-        const char* e = getenv("VSRLAB_AMD_WREG");
-        if (e && e[0] == '1') { const int rc = vsr_launch_conv3x3_c64_wreg(a, num_cus, st); if (rc != VSR_ERR_UNSUPPORTED) return rc; }
-    }
+    // the weights-in-registers experiment for the launches it supports: VSRLAB_AMD_WREG=1 at start-up, or vsr_debug_set_wreg() (A/B in one process)
+    if (__atomic_load_n(&g_wreg_on, __ATOMIC_RELAXED) < 0) __atomic_store_n(&g_wreg_on, vsr_env().wreg ? 1 : 0, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&g_wreg_on, __ATOMIC_RELAXED) == 1) { const int rc = vsr_launch_conv3x3_c64_wreg(a, num_cus, st); if (rc != VSR_ERR_UNSUPPORTED) return rc; }
     bool res = false, aux = false;
     for (int z = 0; z < a.nz; ++z) { res = res || a.res[z]; aux = aux || a.aux[z]; }
     for (int z = 0; z < a.nz; ++z) if ((res && !a.res[z]) || (aux && !a.aux[z])) return VSR_ERR_UNSUPPORTED;

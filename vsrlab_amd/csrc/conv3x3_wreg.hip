@@ -7,7 +7,7 @@
 // next tile itself, one piece between two K steps (there are no producer waves: nothing else fits beside a 512-register wave).
 // LDS holds just the two haloed tile buffers.  Same tile, same accumulator layout, same epilogue arithmetic as
 // conv3x3_persist.hip (results bit-identical); only the two trunk epilogues (bias+ReLU, bias+identity) and unit steps.
-// Selected per launch by VSRLAB_AMD_WREG=1 (an A/B switch: tools/ab_wreg.py and the parity test flip it).
+// Selected by VSRLAB_AMD_WREG=1 at start-up or vsr_debug_set_wreg() (an A/B switch: tools/ab_wreg.py and the parity test flip it).
 //
 // STATUS (end of round 3): bit-identical to conv3x3_persist on every size tried, and SLOWER per launch: 54.8 us against 39.4-40.6 (540p,
 // out of cache, one box).  Where the difference goes, by ablation (make ABL=<bits> ABLSRC=conv3x3_wreg):

@@ -115,6 +115,7 @@ struct Plan {
     size_t S[2], dWp[2], slab[2];               // per direction / stream
     size_t far_cnt;                             // [2][t] ints: far-source counters of the gather-form warp backward
     size_t chain_sync[2] = {0, 0};              // counters of the trunk chain launches (0: chains not planned)
+    int chain_mode = 1;                         // VSRLAB_AMD_CHAIN, read ONCE per engine call (build()): 0 one launch per layer, 1 chains, 2 diagnostic
     size_t G_C0, G_U1, G_U0, G_P;
     size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow / input gradient)
     size_t stem_wd_lr[2];       // data-gradient weights of the stems' 3 LR input channels (input gradient)
@@ -130,6 +131,7 @@ struct Plan {
 
     int build(const VsrBasicVSRDesc& desc, int mode) {     // 0 inference, 1 training (frozen flow), 2 training incl. SPyNet
         d = desc; bwd = mode >= 1; flowgrad = mode >= 2;
+        { const char* e = getenv("VSRLAB_AMD_CHAIN"); chain_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
         if (d.arena_mode != 0 && d.arena_mode != 1) return VSR_ERR_BADARG;
         diet = bwd && d.arena_mode == 1;
         rb = d.res_blocks; n = d.n; t = d.t; h = d.h; w = d.w; dtype = d.dtype;
@@ -448,16 +450,11 @@ int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm) {
 }
 
 // The 2 rb convolutions of a frame's residual blocks (and their data gradients) as ONE launch (conv3x3_chain.hip): training
-// arena only (every layer has a buffer of its own there), bf16.  VSRLAB_AMD_CHAIN=0 (read per call) = one launch per layer.
-bool chain_on(const Plan& p) {
-    if (!p.chain_sync[0] || !p.chain_sync[1] || 2 * p.rb > VSR_CHAIN_MAX_LAYERS) return false;
-    const char* e = getenv("VSRLAB_AMD_CHAIN");
-    return !(e && e[0] == '0');
-}
+// arena only (every layer has a buffer of its own there), bf16.  VSRLAB_AMD_CHAIN=0 (read once per engine call, Plan::build) = one launch per layer.
+bool chain_on(const Plan& p) { return p.chain_mode != 0 && p.chain_sync[0] && p.chain_sync[1] && 2 * p.rb <= VSR_CHAIN_MAX_LAYERS; }
 unsigned chain_off(size_t o) { return (unsigned)(o >> 8); }
-int chain_launch(const ChainArgs& a, hipStream_t st) {
-    const char* e = getenv("VSRLAB_AMD_CHAIN");
-    if (e && e[0] == '2') {            // diagnostic: the same kernel, one layer per launch (no hand-off between workgroups)
+int chain_launch(const Plan& p, const ChainArgs& a, hipStream_t st) {
+    if (p.chain_mode == 2) {            // diagnostic: the same kernel, one layer per launch (no hand-off between workgroups)
         for (int l = 0; l < a.nlayers; ++l) {
             ChainArgs b = a;
             b.nlayers = 1; b.layer[0] = a.layer[l];
@@ -478,7 +475,7 @@ int trunk_chain_forward(const Ctx& c, const Plan& p, int dir, int i) {
         l2 = {chain_off(p.aoff(dir, i, b)), chain_off(p.xoff(dir, i, b + 1)), chain_off(p.xoff(dir, i, b)), 0xffffffffu, 0xffffffffu,
               chain_off(p.blk_w[dir][2 * b + 1]), chain_off(p.blk_b[dir][2 * b + 1]), CHAIN_SKIP};
     }
-    return chain_launch(a, c.st);
+    return chain_launch(p, a, c.st);
 }
 // dA_b = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b), dX_b = dX_{b+1} + dgrad(conv1)(dA_b) for b = rb-1 .. 1, and dA_0: 2 rb - 1 layers
 int trunk_chain_backward(const Ctx& c, const Plan& p, int dir, int i) {
@@ -493,7 +490,7 @@ int trunk_chain_backward(const Ctx& c, const Plan& p, int dir, int i) {
                             chain_off(p.blk_wd[dir][2 * b]), 0xffffffffu, CHAIN_SKIP};
     }
     a.nlayers = L;
-    return chain_launch(a, c.st);
+    return chain_launch(p, a, c.st);
 }
 
 // one call of ResidualBlock (conv.py:94-103) on cat([lr_i, warped feat])
