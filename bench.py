@@ -431,7 +431,8 @@ def main():
                                 "achieved_GBs_per_gpu": round(bpf * frames_per_s / world / 1e9, 1),
                                 "hbm_frac": round(bpf * frames_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                                 "achieved_TFLOPs_per_gpu": round(fpf * frames_per_s / world / 1e12, 1)}
-        live = chains_in_step_live(model, crit, lrs, hr, opt, args) if args.dtype == "bf16" else None
+        # (not under stock DDP at world > 1: a backward outside its forward would meet the reducer's hooks)
+        live = chains_in_step_live(model, crit, lrs, hr, opt, args) if args.dtype == "bf16" and (world == 1 or sync is not None) else None
         if args.dtype == "bf16":                             # the dominant kernel's leg: rank 0's GPU, after the timed region, at every N
             out["roofline"] = dominant_kernel_roofline(dev, h, w)
             log(f"dominant kernel: {out['roofline']['avg_us']} us")
