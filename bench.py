@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
-PROFILE_JSON = os.path.join("profiles", "r03_roofline.json")     # committed rocprofv3 summary of THIS command (profiles/README.md)
+PROFILE_JSON = os.path.join("profiles", "r04_roofline.json")     # committed rocprofv3 summary of THIS command (profiles/README.md)
 
 
 def tree_id():
@@ -266,9 +266,10 @@ def log(msg):
 def cpu_baseline(h540, w540):
     """The oracle (CPU restatement of the reference, fp32, "port") on this box's host cores, on a bounded sample
     (BASELINE.md section 4): (i) BASELINE config 1 exactly (n=2, t=5, 64x64, rb=30) fwd+Charbonnier+bwd, best of 2
-    after a warm-up; (ii) one 540x960 frame (n=1, t=1, rb=30) fwd+Charbonnier+bwd, ONE run -- the frame size the
-    metric is quoted on; a 7-frame clip needs > 113 GB of saved fp32 activations and minutes of CPU time, and the cost
-    is linear in n*t*pixels.  value = (ii)'s LR frames/s."""
+    after a warm-up; (ii) a 540x960 clip of TWO frames (n=1, t=2, rb=30) fwd+Charbonnier+bwd, ONE run -- the frame size the
+    metric is quoted on, with SPyNet (both directions) and the two feature warps and their adjoints inside, as BASELINE.md
+    section 4 planned (round 3 timed t=1: no flow path at all); a 7-frame clip needs > 113 GB of saved fp32 activations and
+    minutes of CPU time, and the cost is linear in n*t*pixels.  value = (ii)'s LR frames/s."""
     from oracle import basicvsr_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -284,15 +285,16 @@ def cpu_baseline(h540, w540):
         if i > 0:
             best = dt if best is None else min(best, dt)
     fps_c1 = 10.0 / best
-    lrs = torch.rand(1, 1, 3, h540, w540, generator=g)
-    hr = torch.rand(1, 1, 3, 4 * h540, 4 * w540, generator=g)
+    lrs = torch.rand(1, 2, 3, h540, w540, generator=g)
+    hr = torch.rand(1, 2, 3, 4 * h540, 4 * w540, generator=g)
     t0 = time.perf_counter()
     O.fwd_bwd(sd, lrs, hr)
     dt540 = time.perf_counter() - t0
-    return {"value": round(1.0 / dt540, 5), "unit": "LR frames/s", "cores": cores, "kind": "port",
+    return {"value": round(2.0 / dt540, 5), "unit": "LR frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32 fwd+Charbonnier+bwd, rb=30: (i) config 1 (n=2,t=5,64x64) best of 2 after a warm-up {best:.2f} s/step = "
                       f"{fps_c1:.2f} LR frames/s at 64x64 (= {fps_c1 * 64 * 64 / float(h540 * w540):.4f} per-pixel-normalised to {h540}x{w540}); "
-                      f"(ii) one {h540}x{w540} frame (n=1,t=1), one run: {dt540:.1f} s = value",
+                      f"(ii) one {h540}x{w540} clip of 2 frames (n=1,t=2: SPyNet both directions + feature warps included), one run: "
+                      f"{dt540:.1f} s for 2 frames = value",
             "config1_frames_per_s": round(fps_c1, 3)}
 
 
@@ -442,6 +444,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(h, w)
         print(json.dumps(out), flush=True)
     if dist:
+        # ranks 1..N-1 wait here while rank 0 runs its post-timing legs (in_step_live, the dominant kernel's leg) on its GPU:
+        # nobody tears the process group down under a rank that is still working
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -610,8 +610,9 @@ def test_basicvsr_540p_vs_oracle(dtype):
 
 def test_config2_full_size_properties():
     """BASELINE config 2 at FULL size through the C ABI (n=1, t=7, 540x960, 30 blocks, bf16: the benchmarked
-    configuration, ~128 GiB arena): finite outputs; a second backward on the same retained forward reproduces EVERY gradient
-    bit for bit; the backward is linear in the cotangent.  One forward, four backwards."""
+    configuration, ~128 GiB arena): finite outputs; the trunk-chain launches reproduce the one-launch-per-layer engine bit for
+    bit (sr and all 254 gradients); a second backward on the same retained forward reproduces EVERY gradient bit for bit; the
+    backward is linear in the cotangent.  Two forwards, five backwards."""
     dev = _gpu()
     import vsrlab_amd
     from vsrlab_amd import functional as VF
@@ -628,10 +629,9 @@ def test_config2_full_size_properties():
     lrs = torch.rand(n, t, 3, h, w, device=dev)
     sr = torch.empty(n, t, 3, 4 * h, 4 * w, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert lib.vsr_basicvsr_forward(ctypes.byref(desc), VF._ptr_array(ps), len(ps), VF._ptr(lrs), VF._ptr(sr), VF._ptr(ws), nbytes, 1, st) == 0
-    assert bool(torch.isfinite(sr).all())
-    # same weights, frame 0 alone at inference (no arena retention): the first frame of the backward-time chain differs
-    # (it sees the later frames), so only shapes / finiteness are compared here; values are pinned at t=3 above.
+
+    def fwd():
+        assert lib.vsr_basicvsr_forward(ctypes.byref(desc), VF._ptr_array(ps), len(ps), VF._ptr(lrs), VF._ptr(sr), VF._ptr(ws), nbytes, 1, st) == 0
 
     def bwd(cot):
         gs = [torch.zeros_like(p) if k < n_train else None for k, p in enumerate(ps)]
@@ -639,9 +639,31 @@ def test_config2_full_size_properties():
                                          VF._ptr(None), VF._ptr(ws), nbytes, st) == 0
         return {keys[k]: g for k, g in enumerate(gs) if g is not None}
 
+    # The chain launches AT THE BENCHMARKED SIZE (60 layers x 2040 tiles on 256 workgroups: deferred publishes, two-tile look-ahead,
+    # middle-out region order, layer-boundary weight reloads) against one launch per layer (VSRLAB_AMD_CHAIN is read per engine
+    # call): the same tile arithmetic on the same operands, so sr and all 254 gradients must be bit-identical.
+    t0 = VF.chain_timeouts()
     c1 = torch.randn_like(sr)
+    os.environ["VSRLAB_AMD_CHAIN"] = "0"
+    try:
+        fwd()
+        sr_per_layer = sr.clone()
+        g_per_layer = bwd(c1)
+    finally:
+        os.environ.pop("VSRLAB_AMD_CHAIN", None)
+    sr.zero_()
+    fwd()
+    assert bool(torch.isfinite(sr).all())
+    assert torch.equal(sr, sr_per_layer)
+    del sr_per_layer
+    # same weights, frame 0 alone at inference (no arena retention): the first frame of the backward-time chain differs
+    # (it sees the later frames), so only shapes / finiteness are compared here; values are pinned at t=3 above.
+
     c2 = torch.randn_like(sr)
     g1, g1b, g2 = bwd(c1), bwd(c1), bwd(c2)
+    for k in g1:
+        assert torch.equal(g1[k], g_per_layer[k]), ("chain vs one launch per layer", k)
+    assert VF.chain_timeouts() == t0
     c12 = 0.5 * c1 + c2
     g12 = bwd(c12)
     del c12
@@ -731,7 +753,7 @@ def test_backward_is_linear_in_cotangent_large():
     assert bool(torch.isfinite(g12).all())
     # every product dY*X is formed from bf16-rounded activation gradients: linear up to bf16 rounding
     assert rel_l2(g12, 0.5 * g1 + g2) < 2e-2
-    assert rel_l2(bwd(c1), g1) < 1e-3          # atomics in the warp scatter: order noise only
+    assert torch.equal(bwd(c1), g1)            # nothing in a frozen-flow backward depends on an arrival order (determinism)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -803,6 +825,51 @@ def test_far_flows_match_the_oracle_and_repeat_bit_for_bit(dtype):
             sr_e, _, g_e = O.fwd_bwd(sd, lrs, cot, cot=cot)
         assert rel_err(sr, sr_x) <= 1.5 * max(rel_err(sr_e, sr_x), 1e-3)
         _noise_floor_check(grads, g_e, g_x, max_glob_ratio=1.5, max_tensor_ratio=2.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gather_form_warp_adjoint_vs_scatter_form_and_non_finite_far_sources(dtype):
+    """The engine's gather-form warp adjoint (elementwise.hip warp_bwd_gather_kernel + warp_bwd_far_kernel) on its own, through the
+    vsr_debug_warp_bwd_gather hook: (a) equal to the scatter form (vsr_flow_warp_bwd_ex: fp32 atomics) on flows that mix near and
+    far sources, S back to all-zero; (b) round-3 ADVICE: a NaN / Inf cotangent at a FAR source used to be converted to a finite
+    fixed-point number -- it must come out non-finite (FusedAdam's skip-on-non-finite-norm relies on it); a near one always did."""
+    dev = _gpu()
+    from vsrlab_amd import _lib, functional as VF
+    lib = _lib.load()
+    fn = lib.vsr_debug_warp_bwd_gather
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    dt = VF.DT_F32 if dtype == "fp32" else VF.DT_BF16
+    n, h, w = 2, 37, 70
+    flow = rand(1401, n, 2, h, w, lo=-3, hi=3)
+    flow[:, 0, :, 20:45] += 7.0                                       # a band of far sources (|dx| > 4)
+    flow = flow.to(dev).contiguous()
+    cot = rand(1402, n, 64, h, w, lo=-1, hi=1).to(dev)
+
+    def gather(c):
+        g = VF.to_pixel_major(c, dt)
+        out = torch.empty_like(g)
+        S = torch.zeros(n * h * w * 64, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert fn(dt, VF._ptr(g), VF._ptr(flow), None, VF._ptr(S), VF._ptr(cnt), VF._ptr(out), n, h, w, VF._stream()) == 0
+        out.pm_w = w
+        return VF.from_pixel_major(out, 64).float(), S, int(cnt.item())
+
+    got, S, far = gather(cot)
+    assert far & 0x3fffffff > 0 and not (far & 0x40000000) and int(S.abs().max()) == 0
+    g = VF.to_pixel_major(cot, dt)
+    acc = torch.zeros((n, h, w, 64), dtype=torch.float32, device=dev)
+    assert lib.vsr_flow_warp_bwd_ex(dt, VF._ptr(g), VF._ptr(flow), VF._ptr(acc), n, h, w, 64, 0, VF._stream()) == 0
+    want = acc.permute(0, 3, 1, 2)
+    assert rel_err(got, want) < tol(dtype, 1e-5, 1e-2)                # (the gather form rounds its output to the storage type)
+    for bad in (float("nan"), float("inf")):
+        for x in (30, 5):                                             # a far source, a near source
+            c = cot.clone()
+            c[1, 7, 11, x] = bad
+            out, S, far = gather(c)
+            assert not bool(torch.isfinite(out).all()), (bad, x)
+            assert int(S.abs().max()) == 0
+            assert bool(far & 0x40000000) == (x == 30)
 
 
 def test_long_clip_more_than_8_frames_fp32():
@@ -886,19 +953,6 @@ def test_standalone_modules_forward_and_backward_vs_oracle(dtype):
         del os.environ["VSRLAB_AMD_DTYPE"]
 
 
-def test_pipelined_tile_loop_of_the_persistent_conv_in_a_subprocess():
-    """VSRLAB_AMD_CONV_PIPE=1 selects the two-phase (software-pipelined) tile loop of the bias+skip persistent conv (off by
-    default: DESIGN 4.1).  The switch is read once per process, so the conv / ResidualConv parity tests run again in a child."""
-    _gpu()
-    import subprocess
-    import sys
-    env = dict(os.environ, VSRLAB_AMD_CONV_PIPE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                        "test_conv3x3_c64_fwd_dgrad_wgrad or test_residual_conv_module_fwd_bwd or test_ragged_sizes_and_single_frame"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("shape", [(2, 20, 41), (3, 37, 70), (4, 200, 330)])
 def test_spynet_7x7_layers_on_the_persistent_kernels(shape):
     """The five SPyNet layer shapes (spynet.py:16-18) on the persistent 7x7 kernels (conv7x7_persist.hip: streamed / resident
@@ -977,12 +1031,12 @@ def test_trunk_chain_launch_is_bit_identical_to_one_launch_per_layer():
     assert _chain_timeouts() == t0
 
 
-@pytest.mark.parametrize("shape,blocks", [((2, 21, 70), 2), ((1, 96, 160), 5), ((1, 135, 240), 32)])
+@pytest.mark.parametrize("shape,blocks", [((2, 21, 70), 2), ((1, 96, 160), 5), ((1, 135, 240), 32), ((1, 540, 960), 8)])
 def test_conv3x3_c64_chain_abi_matches_the_per_layer_calls(shape, blocks):
     """vsr_conv3x3_c64_chain_fwd (functional.ResidualChainC64): 2 x blocks layers in one launch against the same layers as
     2 x blocks calls of vsr_conv3x3_c64_fwd -- every intermediate image bit-identical, on a ragged batch of two, on a size
-    with more tiles than workgroups per layer... and on the maximum of 64 layers; launched twice (the flag words are
-    re-zeroed per launch)."""
+    with more tiles than workgroups per layer, on the maximum of 64 layers, and on the benchmarked 540 x 960 image (2040 tiles
+    per layer = 8 per workgroup, 16 layers); launched twice (the flag words are re-zeroed per launch)."""
     dev = _gpu()
     from vsrlab_amd import functional as VF
     n, h, w = shape
@@ -1046,34 +1100,111 @@ def test_chain_hand_off_under_uneven_load_from_a_second_stream():
     assert _chain_timeouts() == t0
 
 
-@pytest.mark.parametrize("shape", [(2, 21, 70), (1, 135, 250)])
-def test_weights_in_registers_experiment_is_bit_identical(shape):
-    """conv3x3_wreg.hip (VSRLAB_AMD_WREG=1 / vsr_debug_set_wreg): four 512-register waves with the nine taps' A fragments in
-    registers, B fragments from LDS only, the tile DMA issued by the MFMA waves into three buffers -- the two trunk epilogues
-    against conv3x3_persist on the same operands, bit for bit (ragged batch of two; more tiles than fit three buffers per
-    workgroup)."""
+def test_chain_error_word_poisons_the_outputs_and_the_optimizer_skips_the_step():
+    """A chain launch whose error word is set (a dependency wait was given up: its tiles were computed from unfinished inputs) must not
+    look like a result (round-3 VERDICT weak #2 / ADVICE medium).  vsr_debug_chain_inject_error(k) starts the next k chain launches
+    with the word set: chain_poison_kernel, enqueued behind every chain launch, then writes NaN into the chain's last image.  Forced in
+    the forward: sr and the loss are not finite.  Forced in the backward only (clean forward): the gradient norm is not finite and
+    FusedAdam leaves every parameter untouched -- all without a host synchronisation in the product path."""
     dev = _gpu()
-    from vsrlab_amd import functional as VF
-    n, h, w = shape
-    x = VF.to_pixel_major(rand(1200, n, 64, h, w, lo=-1, hi=1).to(dev), VF.DT_BF16)
-    r = VF.to_pixel_major(rand(1201, n, 64, h, w, lo=-1, hi=1).to(dev), VF.DT_BF16)
-    wt = (rand(1202, 64, 64, 3, 3, lo=-1, hi=1) / 24.0).to(dev)
-    b = rand(1203, 64, lo=-0.1, hi=0.1).to(dev)
-    out = {}
-    from vsrlab_amd import _lib
+    from vsrlab_amd import _lib, functional as VF
+    from vsrlab_amd.optim import FusedAdam
+    from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
     lib = _lib.load()
-    for mode in ("0", "1"):
-        lib.vsr_debug_set_wreg(int(mode))
-        try:
-            out[mode] = (VF.from_pixel_major(VF.conv3x3_c64(x, wt, b, act=1)), VF.from_pixel_major(VF.conv3x3_c64(x, wt, b, act=0, res_pm=r)))
-        finally:
-            lib.vsr_debug_set_wreg(0)
-    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+    inject = lib.vsr_debug_chain_inject_error
+    inject.restype, inject.argtypes = ctypes.c_int, [ctypes.c_int]
+    m = BasicVSR(64, 2, 4, False, False)
+    m.load_state_dict(O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4)), strict=True)
+    m = m.to(dev)
+    m.compute_dtype = "bf16"
+    opt = FusedAdam(m.parameters(), lr=1e-3, max_grad_norm=1.0)
+    lrs = rand(1301, 1, 3, 3, 40, 72).to(dev)
+    hr = rand(1302, 1, 3, 3, 160, 288).to(dev)
+    try:
+        # (a) quiet step: finite, parameters move
+        before = opt.flat_params.clone()
+        loss = VF.charbonnier_loss(m(lrs), hr)
+        loss.backward()
+        opt.step()
+        assert bool(torch.isfinite(loss)) and bool(torch.isfinite(opt.last_grad_norm).all()) and not torch.equal(opt.flat_params, before)
+        opt.zero_grad()
+        # (b) the first forward chain launch gives up: sr and the loss show it
+        before = opt.flat_params.clone()
+        assert inject(1) == 0
+        sr = m(lrs)
+        loss = VF.charbonnier_loss(sr, hr)
+        assert inject(0) == 0, "the forward did not launch a chain"
+        assert not bool(torch.isfinite(sr).all()) and not bool(torch.isfinite(loss))
+        loss.backward()
+        opt.step()
+        assert not bool(torch.isfinite(opt.last_grad_norm).all()) and torch.equal(opt.flat_params, before)
+        opt.zero_grad()
+        # (c) clean forward, the first BACKWARD chain launch gives up: the gradients show it, the step is skipped
+        sr = m(lrs)
+        loss = VF.charbonnier_loss(sr, hr)
+        assert bool(torch.isfinite(sr).all())
+        assert inject(1) == 0
+        loss.backward()
+        assert inject(0) == 0, "the backward did not launch a chain"
+        opt.step()
+        assert not bool(torch.isfinite(opt.last_grad_norm).all()) and torch.equal(opt.flat_params, before)
+        assert opt.rewind_skipped_step() is True            # (no real timeout happened: nothing to raise)
+        opt.zero_grad()
+        # (d) and the step after that is clean again
+        loss = VF.charbonnier_loss(m(lrs), hr)
+        loss.backward()
+        opt.step()
+        assert bool(torch.isfinite(opt.last_grad_norm).all()) and not torch.equal(opt.flat_params, before)
+    finally:
+        inject(0)
+        m._pool.clear()
+
+
+_TIMEOUT_CHILD = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from oracle import basicvsr_oracle as O
+from vsrlab_amd import functional as VF
+from vsrlab_amd.vsr.models.RealBasicVSR.modules.basicvsr import BasicVSR
+m = BasicVSR(64, 2, 4, False, False)
+m.load_state_dict(O.keyed_state_dict(O.basicvsr_param_shapes(64, 2, 4)), strict=True)
+m = m.to("cuda:0"); m.compute_dtype = "bf16"
+g = torch.Generator().manual_seed(5)
+lrs = torch.rand(1, 2, 3, 40, 72, generator=g).to("cuda:0")
+sr = m(lrs)
+loss = sr.mean()
+torch.cuda.synchronize()
+n = VF.chain_timeouts()
+print("TIMEOUTS", n, "FINITE", bool(torch.isfinite(sr).all()), bool(torch.isfinite(loss)))
+try:
+    VF.raise_on_chain_timeout("child")
+    print("RAISED 0")
+except RuntimeError as e:
+    print("RAISED 1", e)
+"""
+
+
+def test_a_real_chain_timeout_is_loud_in_a_subprocess():
+    """The same failure through the REAL path: the diagnostic build `make ABL=8 ABLSRC=conv3x3_chain` (bit 3: the MFMA waves never
+    publish their tiles) makes every dependency wait of a layer > 0 run into its 1 s clock.  A forward through that library must
+    drain (no hang), count its give-ups, return a non-finite sr, and functional.raise_on_chain_timeout must raise."""
+    _gpu()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "vsrlab_amd", "lib", "libvsrlab_hip_conv3x3_chain_abl8.so")
+    assert os.path.exists(lib), "build() makes the diagnostic chain library (make ABL=8 ABLSRC=conv3x3_chain)"
+    env = dict(os.environ, VSRLAB_AMD_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_CHILD.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("TIMEOUTS")][0].split()
+    assert int(line[1]) > 0 and line[3] == "False" and line[4] == "False", r.stdout
+    assert "RAISED 1" in r.stdout, r.stdout
 
 
 def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
-    is process-wide, so they run in a child, like the pipelined-conv A/B above."""
+    is process-wide, so they run in a child."""
     _gpu()
     import subprocess
     import sys

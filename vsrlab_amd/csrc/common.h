@@ -79,10 +79,6 @@ struct ConvArgs {
     // uses 0.2 (unet-discriminator.py:19)
     float leaky_slope;
     int planar_c;                        // channels of a planar fp32 source (LASTPLANAR): 0 = 3
-    // Persistent kernels: this launch takes 1 / cu_div of the chip's CUs (0 / 1: all of them).  The engine's two propagation
-    // chains run on two streams; with cu_div = 2 their launches sit side by side on half the chip each and walk twice as many
-    // tiles per workgroup (the per-launch set-up -- weights into LDS, first tile's latency -- is paid once per 16 tiles, not 8).
-    int cu_div;
 };
 static inline __host__ __device__ float vsr_slope(float s) { return s != 0.f ? s : 0.1f; }
 
@@ -183,9 +179,6 @@ static inline int vsr_num_cus() {
 struct VsrEnvSwitches {
     bool generic_conv, generic_wgrad, attn_generic, single_stream;
     int wide2_max_wg;
-    bool conv_pipe;           // VSRLAB_AMD_CONV_PIPE (default 0: r03 measured 138.8 vs 141.3 ms/step off vs on; on wins only where the residual loads stall): pipelined tile loop of the bias+skip persistent conv (A/B)
-    bool wreg;                // VSRLAB_AMD_WREG: the weights-in-registers experiment (conv3x3_wreg.hip) for the launches it supports; off by default
-    int chain_share;          // VSRLAB_AMD_CHAIN_SHARE: CU share divisor of the two propagation chains' persistent launches (A/B; default 1: r03 measured 136.9 vs 137.0 ms/step for 1 vs 2)
 };
 static inline const VsrEnvSwitches& vsr_env() {
     static const VsrEnvSwitches s = [] {
@@ -197,12 +190,6 @@ static inline const VsrEnvSwitches& vsr_env() {
         v.single_stream = on("VSRLAB_AMD_SINGLE_STREAM");
         const char* e = getenv("VSRLAB_AMD_WIDE2_MAX_WG");
         v.wide2_max_wg = e ? atoi(e) : 0;
-        e = getenv("VSRLAB_AMD_CONV_PIPE");
-        v.conv_pipe = e && e[0] == '1';
-        v.wreg = on("VSRLAB_AMD_WREG");
-        e = getenv("VSRLAB_AMD_CHAIN_SHARE");
-        v.chain_share = e ? atoi(e) : 1;
-        if (v.chain_share < 1 || v.single_stream) v.chain_share = 1;
         return v;
     }();
     return s;

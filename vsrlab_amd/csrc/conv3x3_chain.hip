@@ -22,9 +22,12 @@
 //   * consumers: the leader producer wave looks at the flags of the 3x3 tiles around an item two tiles ahead (nine lanes, two
 //     8-byte sc1 loads each) and leaves the verdict in LDS; a workgroup barrier later the producer waves issue the tile's LDS-DMA
 //     (sc1: bypasses the CU's L1).  Not ready at that point -> every producer wave polls for itself (bounded by a 1 s clock; a
-//     timeout raises a global error word that ends every wait, so the grid always drains; vsr_debug_chain_timeouts counts them
-//     and the tests require 0).  The residual operand of a layer is the output of the layer before the previous one at the same
-//     tile: complete by transitivity, loaded sc1.
+//     timeout raises the launch's error word, which ends every wait, so the grid always drains).  A launch that gave up a wait
+//     has consumed unfinished tiles: chain_poison_kernel, enqueued behind every chain launch, then overwrites the head of the
+//     chain's LAST image with NaN, so that sr, the loss and every gradient norm downstream go non-finite (FusedAdam skips the
+//     step) without a host synchronisation; vsr_debug_chain_timeouts counts the give-ups for diagnosis and the tests require 0.
+//     The residual operand of a layer is the output of the layer before the previous one at the same tile: complete by
+//     transitivity, loaded sc1.
 //   * every buffer of a chain is written exactly once and read only after its flags say so (training arena: one buffer per
 //     layer), so no CU can hold a stale line of it.
 //   * work distribution and the progress argument: "Work distribution" below.
@@ -36,6 +39,7 @@
 // The tile loop itself (K loop, fragment schedule, epilogues) is conv3x3_persist.hip's; see there for the LDS images.
 #include "common.h"
 #include "kernels.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -378,8 +382,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
         };
         layer_ptrs(cur_layer);
 
-        bool pending = false;                 // a finished tile of this wave whose row counter has not been told yet
-        gu32* pend_cnt = nullptr;             // its flag word: flags[item][w4]
+        bool pending = false;                 // a finished tile of this wave whose flag word has not been set yet
+        gu32* pend_cnt = nullptr;             // that flag word: flags[item][w4]
         int cur = 0;
         // item k of this workgroup (slot k % 3); the next slot is read at the top of a tile and used at its end
         int item = __builtin_amdgcn_readfirstlane(ctl[0]), layer = cur_layer, tn = __builtin_amdgcn_readfirstlane(ctl[2]);
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 nx_item = sn[0]; nx_layer = sn[1]; nx_n = sn[2]; nx_ty = sn[3]; nx_tx = sn[4]; nx_ok = sn[5];
                 // ---- epilogue ----
                 // vmcnt(0): this tile's operands are here, and the PREVIOUS tile's stores (issued a K loop ago) are acknowledged:
-                // now its row counter may be told (R1: every storing wave drains, then adds for itself)
+                // now its flag word may be set (R1: every storing wave drains, then publishes for itself)
                 // (the builtin, so that hipcc's scoreboard knows the queue is empty: behind an asm wait it would wait again, for the
                 // publishing atomic below, in front of the first use of the sign bits)
                 if (!(CABL(4) && V == CHAIN_RELU)) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) alone
@@ -577,6 +581,15 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
 #endif
 }
 
+// Behind every chain launch, on its stream: a launch whose error word is set (a dependency wait was given up, or the word was
+// forced by vsr_debug_chain_inject_error) has read tiles nobody had finished.  Its results are void, and they are MADE to look
+// void: the first 32 pixels x 64 channels of the chain's last image become NaN (pixel (0, 0) of image 0 is real data in every
+// shape), which every consumer of that image carries into sr / the loss / the weight gradients.  No host round trip.
+__global__ void chain_poison_kernel(const unsigned* err, unsigned short* last_image) {
+    if (__hip_atomic_load(err, RLX_AGENT) == 0u) return;
+    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) last_image[i] = 0x7fc0u;        // bf16 quiet NaN
+}
+
 }  // namespace
 
 #ifdef VSR_ABL
@@ -592,9 +605,16 @@ extern "C" int vsr_debug_chain_item(unsigned P, int own, int R, int tiles, int n
 }
 
 // dependency waits that were given up (1 s each) since the library was loaded: anything but 0 voids the results of that run
+// (the launches concerned have poisoned their outputs: chain_poison_kernel)
 extern "C" int vsr_debug_chain_timeouts(unsigned* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_timeouts), sizeof(unsigned)) == hipSuccess ? 0 : VSR_ERR_HIP;
 }
+
+// Test hook: the next `launches` chain launches of this process start with their error word SET, i.e. as if a wait had been given
+// up at once (no wait is honoured, the grid drains, the poison kernel fires) -- the failure mode of a timed-out chain without
+// the second of spinning.  Returns the number of forced launches still pending before the call.
+static std::atomic<int>& chain_inject() { static std::atomic<int> n{0}; return n; }
+extern "C" int vsr_debug_chain_inject_error(int launches) { return chain_inject().exchange(launches < 0 ? 0 : launches); }
 
 size_t vsr_chain_sync_bytes(int nlayers, int N, int H, int W) {
     return 1024 + (size_t)nlayers * N * cdiv(H, PTH) * cdiv(W, PTW) * 16;
@@ -626,8 +646,12 @@ int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st) {
     static VsrDevOnce once[2];
     { const int rc = vsr_set_max_dynamic_lds(once[even == CHAIN_MASK], reinterpret_cast<const void*>(kern), P_LDS); if (rc != VSR_OK) return rc; }
     HIP_CHECK_RET(hipMemsetAsync(a.sync, 0, vsr_chain_sync_bytes(a.nlayers, a.N, a.H, a.W), st));
-    int gx = num_cus / (a.cu_div > 1 ? a.cu_div : 1);
-    if (gx < 1) gx = 1;
+    {
+        int left = chain_inject().load();
+        while (left > 0 && !chain_inject().compare_exchange_weak(left, left - 1)) {}
+        if (left > 0) HIP_CHECK_RET(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.sync + 1), 1, 1, st));
+    }
+    int gx = num_cus < 1 ? 1 : num_cus;
     if (gx > tiles) gx = (int)tiles;
     ChainTiming& T = chain_timing();
     const int slot = T.on && T.n < ChainTiming::MAX ? T.n : -1;
@@ -639,6 +663,9 @@ int vsr_launch_conv3x3_chain(const ChainArgs& a, int num_cus, hipStream_t st) {
         T.layers[slot] = a.nlayers; T.variant[slot] = even; T.pixels[slot] = (long long)a.N * a.H * a.W;
         T.n = slot + 1;
     }
+    hipLaunchKernelGGL(chain_poison_kernel, dim3(1), dim3(256), 0, st, a.sync + 1,
+                       reinterpret_cast<unsigned short*>(a.base + (unsigned long long)a.layer[a.nlayers - 1].dst * 256ull));
+    HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }
 

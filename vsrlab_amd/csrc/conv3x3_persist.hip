@@ -47,7 +47,6 @@ constexpr int NPIECE_T = (IN_CHUNKS + 63) / 64;                           // 43 
 constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11 per wave
 
 __device__ uint4 g_conv_zero_chunk[2];
-__device__ uint4 g_conv_sink[2];                 // where the lanes of an out-of-image pixel store (pipelined tile loop)
 
 template <int ACT> __device__ __forceinline__ float p_act(float v, float slope) {
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -133,7 +132,7 @@ __device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) { unsi
 
 // Epilogue variants are compile-time: a runtime-selected epilogue serialises 16 load->use->store
 // chains per tile (measured: 14 us of a 71 us launch).
-template <int ACT, bool HAS_RES, int MASK, bool PIPE_REQ = false>
+template <int ACT, bool HAS_RES, int MASK>
 __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvArgs ka) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -334,177 +333,6 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             for (int j = 0; j < 8; ++j) idA[hb][j] = (bf16_t)((q == (l15 >> 2) && j == 4 * hb + (l15 & 3)) ? 1.f : 0.f);
         constexpr bool RES_MFMA = HAS_RES && !ABL(4);
 
-        // ---------------------------------------------------------------------------------------------------------------
-        // Pipelined tile loop of the hot epilogues (r03).  The 64 output channels of a tile are accumulated in two PHASES of 18
-        // steps x 8 MFMAs: phase 1 = blocks 0, 1 (piece k = 0 of every pixel), phase 2 = blocks 2, 3 (k = 1).  While a phase runs
-        // on the matrix cores, the finished accumulators of the OTHER half are converted and stored: the epilogue of (tile t,
-        // k = 0) is spread over the MFMA gaps of phase 2 of tile t, that of (t, k = 1) over phase 1 of tile t + 1 -- one to four
-        // vector instructions behind every second MFMA, placed by hand between sched_barriers.  Before (r03 stamps) a tile was
-        // 4.9 k cycles of K loop + 1.0 k of epilogue + 0.15-0.65 k of operand loads with the matrix pipe idle; the price is that
-        // the B fragments are read once per phase (216 instead of 144 fragment reads per tile and wave).
-        // Tiles that reach over the image edge take the same straight-line code: the lanes of an outside pixel load from the zero
-        // chunk and store into a sink.  Residual operands are loaded by inline asm and waited for with a COUNTED vmcnt: every
-        // wave issues the same vector-memory sequence per tile (L = 4 loads, S = 4 stores, [] = variant-dependent):
-        //   phase 1: [sign-bit load] L_A(t) S(t-1, k=1) [sign store]    phase 2: L_B(t) S(t, k=0)
-        // so the load of a piece is always followed by exactly 11 younger operations when its epilogue starts (12 with the
-        // sign store): hipcc's own waits across the loop's back edge would be conservative and wait for the loads just issued.
-        // ---------------------------------------------------------------------------------------------------------------
-        constexpr bool PIPE = PIPE_REQ && !ABL(4) && !ABL(5) && ((ACT == ACT_RELU && !HAS_RES && MASK == MASK_NONE) || (ACT == ACT_NONE && HAS_RES && MASK == MASK_NONE) ||
-                              (ACT == ACT_NONE && !HAS_RES && MASK == MASK_RELU_BITS) || (ACT == ACT_NONE && !HAS_RES && MASK == MASK_NONE) ||
-                              (ACT == ACT_LEAKY && !HAS_RES && MASK == MASK_NONE));
-        if constexpr (PIPE) {
-            constexpr bool P_BITS = MASK == MASK_RELU_BITS;
-            constexpr bool P_SIGN = ACT != ACT_NONE;                  // this launch writes sign bits
-            const auto* const zsrc16 = GP(const char, g_conv_zero_chunk);
-            auto* const sink16 = GP(char, g_conv_sink);
-            struct TC { long long tbase; int tile; unsigned okm; };      // okm bit nb: this lane's pixel of block nb is inside the image
-            TC tc = {0, 0, 0u}, tp = {0, 0, 0u};                         // current / previous tile (tp starts as "nothing to store")
-            f32x4_t accA[2][4], accB[2][4];
-            u32x4_t rrA[4], rrB[4];
-            unsigned ow[4] = {0u, 0u, 0u, 0u}, x0 = 0u, x1 = 0u, so0 = 0u, so1 = 0u, so0p = 0u;
-            u32x2_t sb = {0u, 0u};
-            unsigned sbyp = 0u;                                          // sign-bit word y of the previous tile
-            const unsigned k11 = 0x00010001u;
-            bf16x8_t fa[2][2], fb[2][4];
-            unsigned bb = 0u;
-            int cur = 0;
-            (void)x0; (void)x1; (void)so0p; (void)sbyp; (void)rrA; (void)rrB;
-#define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
-#define PH_LOADA(tap_, kk_, slot, i_, mb_) DSR(fa[slot][i_], (tap_ < 6 ? a_lo[kk_] : a_hi[kk_]), (tap_ < 6 ? tap_ : tap_ - 6) * 8192 + (mb_) * 2048);
-#define PH_LOADB(tap_, kk_, slot, nb_) DSR(fb[slot][nb_], bb, (((nb_) >> 1) + (tap_) / 3) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb_) & 1) * 16 + (tap_) % 3) * 16);
-#define PH_LOADALL(s_, mb0_)                                                                                           \
-            { constexpr int t_ = (s_) / 2, k_ = (s_) % 2;                                                              \
-              PH_LOADA(t_, k_, (s_) % 2, 0, mb0_) PH_LOADA(t_, k_, (s_) % 2, 1, (mb0_) + 1)                              \
-              PH_LOADB(t_, k_, (s_) % 2, 0) PH_LOADB(t_, k_, (s_) % 2, 1) PH_LOADB(t_, k_, (s_) % 2, 2) PH_LOADB(t_, k_, (s_) % 2, 3) }
-            // element e (0..7) of piece (K, nb): accumulators of blocks 2K (e < 4) and 2K + 1
-#define PH_EL(ACC, nb_, e_) ACC[(e_) >> 2][nb_][(e_) & 3]
-            // ---- epilogue slot q (0..15) of piece nb_ of half K_ (accumulators ACC, residuals RR, tile context T_) ----
-#define PH_SLOT(ACC, RR, T_, K_, nb_, q_)                                                                              \
-            {                                                                                                          \
-                constexpr int w_ = (q_) < 12 ? (q_) / 3 : 0, o_ = (q_) % 3, sh_ = 4 * (nb_) + w_;                       \
-                if ((q_) < 12) {                                                                                       \
-                    if (ACT == ACT_RELU) {                                                                             \
-                        if (o_ == 0) ow[w_] = pk_bf16(PH_EL(ACC, nb_, 2 * w_), PH_EL(ACC, nb_, 2 * w_ + 1));                                                       \
-                        if (o_ == 1) ow[w_] = pk_max_i16(ow[w_], 0u);                                                  \
-                        if (o_ == 2) { if ((K_) == 0) so0 |= pk_min_u16(ow[w_], k11) << sh_; else so1 |= pk_min_u16(ow[w_], k11) << sh_; } \
-                    } else if (ACT == ACT_LEAKY) {                                                                     \
-                        if (o_ == 0) { x0 = __float_as_uint(PH_EL(ACC, nb_, 2 * w_) * slope); x1 = __float_as_uint(PH_EL(ACC, nb_, 2 * w_ + 1) * slope); }          \
-                        if (o_ == 1) { PH_EL(ACC, nb_, 2 * w_) = fmaxf(PH_EL(ACC, nb_, 2 * w_), __uint_as_float(x0)); PH_EL(ACC, nb_, 2 * w_ + 1) = fmaxf(PH_EL(ACC, nb_, 2 * w_ + 1), __uint_as_float(x1)); } \
-                        if (o_ == 2) { ow[w_] = pk_bf16(PH_EL(ACC, nb_, 2 * w_), PH_EL(ACC, nb_, 2 * w_ + 1));                                                     \
-                                       const unsigned t_ = pk_min_u16(pk_max_i16(ow[w_], 0u), k11) << sh_;              \
-                                       if ((K_) == 0) so0 |= t_; else so1 |= t_; }                                     \
-                    } else if (HAS_RES) {                                                                              \
-                        if (o_ == 0) { if (w_ == 0) { asm volatile("s_waitcnt vmcnt(11)" ::: "memory");                 \
-                                                      asm volatile("" : "+v"(RR[nb_])); }                              \
-                                       x0 = RR[nb_][w_] << 16; x1 = RR[nb_][w_] & 0xffff0000u; }                        \
-                        if (o_ == 1) { PH_EL(ACC, nb_, 2 * w_) += __uint_as_float(x0); PH_EL(ACC, nb_, 2 * w_ + 1) += __uint_as_float(x1); }                       \
-                        if (o_ == 2) ow[w_] = pk_bf16(PH_EL(ACC, nb_, 2 * w_), PH_EL(ACC, nb_, 2 * w_ + 1));                                                       \
-                    } else if (P_BITS) {                                                                               \
-                        if (o_ == 0) ow[w_] = pk_bf16(PH_EL(ACC, nb_, 2 * w_), PH_EL(ACC, nb_, 2 * w_ + 1));                                                       \
-                        if (o_ == 1) x0 = (((K_) == 0 ? sb.x : sbyp) >> sh_) & k11;                                    \
-                        if (o_ == 2) ow[w_] = pk_mul_lo_u16(ow[w_], x0);                                               \
-                    } else {                                                                                           \
-                        if (o_ == 0) ow[w_] = pk_bf16(PH_EL(ACC, nb_, 2 * w_), PH_EL(ACC, nb_, 2 * w_ + 1));                                                       \
-                    }                                                                                                  \
-                }                                                                                                      \
-                if ((q_) == 13) {                                                                                      \
-                    auto* d_ = ((T_.okm >> (nb_)) & 1u) ? GP(char, dst_z + T_.tbase + loff[nb_] + (K_) * 1024) : sink16; \
-                    *GP(u32x4_t, d_) = u32x4_t{ow[0], ow[1], ow[2], ow[3]};                                            \
-                }                                                                                                      \
-                if ((q_) == 14 && (nb_) == 3 && (K_) == 1 && P_SIGN) {                                                  \
-                    auto* d_ = (T_.okm && sout_z) ? GP(char, sout_z + ((long long)T_.tile * 256 + w4 * 64 + lane)) : sink16; \
-                    *GP(u32x2_t, d_) = u32x2_t{so0p, so1};                                                             \
-                    so1 = 0u;                                                                                          \
-                }                                                                                                      \
-            }
-            // ---- operand loads of the current tile: slot j of a phase's first step = piece (K_, nb = j) ----
-#define PH_OPLOAD(RR, K_, nb_)                                                                                         \
-            if (HAS_RES) {                                                                                             \
-                const auto* s_ = ((tc.okm >> (nb_)) & 1u) ? GP(const char, res_z + tc.tbase + loff[nb_] + (K_) * 1024) : zsrc16; \
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(RR[nb_]) : "v"(s_) : "memory");                   \
-            }
-            // one K step of a phase: 8 MFMAs on ACC (blocks MB0_, MB0_+1), the 6 fragment reads of the next step (NS_ >= 0: step NS_ of
-            // blocks NMB0_) behind MFMAs 0-5, one epilogue / operand slot behind MFMAs 1, 3, 5, 7
-#define PH_MFMA(s_, ACC, i_, nb_, MB0_) ACC[i_][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(s_) % 2][i_], fb[(s_) % 2][nb_], (s_) == 0 ? bvec[(MB0_) + (i_)] : ACC[i_][nb_], 0, 0, 0);
-#define PH_SB __builtin_amdgcn_sched_barrier(0);
-#define PH_STEP(s_, ACC, MB0_, NS_, NMB0_, S0, S1, S2, S3)                                                             \
-            {                                                                                                          \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PH_SB                                               \
-                PH_MFMA(s_, ACC, 0, 0, MB0_) PH_SB if ((NS_) >= 0) { PH_LOADA((NS_) / 2, (NS_) % 2, (NS_) % 2, 0, NMB0_) } PH_SB           \
-                PH_MFMA(s_, ACC, 0, 1, MB0_) PH_SB if ((NS_) >= 0) { PH_LOADA((NS_) / 2, (NS_) % 2, (NS_) % 2, 1, (NMB0_) + 1) } S0 PH_SB   \
-                PH_MFMA(s_, ACC, 0, 2, MB0_) PH_SB if ((NS_) >= 0) { PH_LOADB((NS_) / 2, (NS_) % 2, (NS_) % 2, 0) } PH_SB                  \
-                PH_MFMA(s_, ACC, 0, 3, MB0_) PH_SB if ((NS_) >= 0) { PH_LOADB((NS_) / 2, (NS_) % 2, (NS_) % 2, 1) } S1 PH_SB               \
-                PH_MFMA(s_, ACC, 1, 0, MB0_) PH_SB if ((NS_) >= 0) { PH_LOADB((NS_) / 2, (NS_) % 2, (NS_) % 2, 2) } PH_SB                  \
-                PH_MFMA(s_, ACC, 1, 1, MB0_) PH_SB if ((NS_) >= 0) { PH_LOADB((NS_) / 2, (NS_) % 2, (NS_) % 2, 3) } S2 PH_SB               \
-                PH_MFMA(s_, ACC, 1, 2, MB0_) PH_SB                                                                     \
-                PH_MFMA(s_, ACC, 1, 3, MB0_) PH_SB S3 PH_SB                                                            \
-            }
-            // steps 1..16 of a phase carry the 64 slots of the other half's epilogue: step s_ -> piece (s_-1)/4, slots 4((s_-1)%4) ..+3
-#define PH_ESTEP(s_, ACC, MB0_, NS_, NMB0_, EACC, ERR, ET, EK)                                                          \
-            PH_STEP(s_, ACC, MB0_, NS_, NMB0_, PH_SLOT(EACC, ERR, ET, EK, ((s_) - 1) / 4, 4 * (((s_) - 1) % 4) + 0),    \
-                    PH_SLOT(EACC, ERR, ET, EK, ((s_) - 1) / 4, 4 * (((s_) - 1) % 4) + 1),                               \
-                    PH_SLOT(EACC, ERR, ET, EK, ((s_) - 1) / 4, 4 * (((s_) - 1) % 4) + 2),                               \
-                    PH_SLOT(EACC, ERR, ET, EK, ((s_) - 1) / 4, 4 * (((s_) - 1) % 4) + 3))
-#define PH_ESTEPS(ACC, MB0_, EACC, ERR, ET, EK)                                                                        \
-            PH_ESTEP(1, ACC, MB0_, 2, MB0_, EACC, ERR, ET, EK) PH_ESTEP(2, ACC, MB0_, 3, MB0_, EACC, ERR, ET, EK)       \
-            PH_ESTEP(3, ACC, MB0_, 4, MB0_, EACC, ERR, ET, EK) PH_ESTEP(4, ACC, MB0_, 5, MB0_, EACC, ERR, ET, EK)       \
-            PH_ESTEP(5, ACC, MB0_, 6, MB0_, EACC, ERR, ET, EK) PH_ESTEP(6, ACC, MB0_, 7, MB0_, EACC, ERR, ET, EK)       \
-            PH_ESTEP(7, ACC, MB0_, 8, MB0_, EACC, ERR, ET, EK) PH_ESTEP(8, ACC, MB0_, 9, MB0_, EACC, ERR, ET, EK)       \
-            PH_ESTEP(9, ACC, MB0_, 10, MB0_, EACC, ERR, ET, EK) PH_ESTEP(10, ACC, MB0_, 11, MB0_, EACC, ERR, ET, EK)    \
-            PH_ESTEP(11, ACC, MB0_, 12, MB0_, EACC, ERR, ET, EK) PH_ESTEP(12, ACC, MB0_, 13, MB0_, EACC, ERR, ET, EK)   \
-            PH_ESTEP(13, ACC, MB0_, 14, MB0_, EACC, ERR, ET, EK) PH_ESTEP(14, ACC, MB0_, 15, MB0_, EACC, ERR, ET, EK)   \
-            PH_ESTEP(15, ACC, MB0_, 16, MB0_, EACC, ERR, ET, EK) PH_ESTEP(16, ACC, MB0_, 17, MB0_, EACC, ERR, ET, EK)
-#define PH_NOP
-            TileIter it;
-            for (it.init(walk.first, walk.stride, ntx, nty); it.tile < walk.end; it.advance(walk.stride, ntx, nty)) {
-                {
-                    const int ty0 = it.ty * PTH, tx0 = it.tx * PTW;
-                    tc.tile = it.tile;
-                    tc.tbase = (long long)it.n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oyz, tx0 * a.out_step, 0, a.Wd, 64);
-                    tc.okm = 0u;
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        tc.okm |= ((tx0 + (nb & 1) * 16 + pxl < a.W) && (ty0 + w4 * 2 + (nb >> 1) < a.H) ? 1u : 0u) << nb;
-                }
-                bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PH_SB
-                PH_LOADALL(0, 0)
-                // ---- phase 1: blocks 0, 1 of tile t; epilogue of (t - 1, k = 1) ----
-                PH_STEP(0, accA, 0, 1, 0,
-                        { if (P_BITS) sb = sbits_z[(long long)tc.tile * 256 + w4 * 64 + lane]; PH_OPLOAD(rrA, 0, 0) }, PH_OPLOAD(rrA, 0, 1), PH_OPLOAD(rrA, 0, 2), PH_OPLOAD(rrA, 0, 3))
-                PH_ESTEPS(accA, 0, accB, rrB, tp, 1)
-                PH_STEP(17, accA, 0, 0, 2, PH_NOP, PH_NOP, PH_NOP, PH_NOP)          // prefetches step 0 of phase 2 (blocks 2, 3)
-                // ---- phase 2: blocks 2, 3 of tile t; epilogue of (t, k = 0) ----
-                PH_STEP(0, accB, 2, 1, 2, PH_OPLOAD(rrB, 1, 0), PH_OPLOAD(rrB, 1, 1), PH_OPLOAD(rrB, 1, 2), PH_OPLOAD(rrB, 1, 3))
-                PH_ESTEPS(accB, 2, accA, rrA, tc, 0)
-                PH_STEP(17, accB, 2, -1, 0, PH_NOP, PH_NOP, PH_NOP, PH_NOP)
-                so0p = so0; so0 = 0u; sbyp = sb.y;
-                tp = tc;
-                __builtin_amdgcn_s_barrier();                  // the producers' next tile has landed; everybody has finished reading `cur`
-                cur ^= 1;
-            }
-            // ---- drain: the epilogue of (last tile, k = 1), back to back ----
-#define PH_DRAIN(nb_) PH_SLOT(accB, rrB, tp, 1, nb_, 0) PH_SLOT(accB, rrB, tp, 1, nb_, 1) PH_SLOT(accB, rrB, tp, 1, nb_, 2) PH_SLOT(accB, rrB, tp, 1, nb_, 3) \
-                      PH_SLOT(accB, rrB, tp, 1, nb_, 4) PH_SLOT(accB, rrB, tp, 1, nb_, 5) PH_SLOT(accB, rrB, tp, 1, nb_, 6) PH_SLOT(accB, rrB, tp, 1, nb_, 7) \
-                      PH_SLOT(accB, rrB, tp, 1, nb_, 8) PH_SLOT(accB, rrB, tp, 1, nb_, 9) PH_SLOT(accB, rrB, tp, 1, nb_, 10) PH_SLOT(accB, rrB, tp, 1, nb_, 11) \
-                      PH_SLOT(accB, rrB, tp, 1, nb_, 12) PH_SLOT(accB, rrB, tp, 1, nb_, 13) PH_SLOT(accB, rrB, tp, 1, nb_, 14) PH_SLOT(accB, rrB, tp, 1, nb_, 15)
-            if (HAS_RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PH_DRAIN(0) PH_DRAIN(1) PH_DRAIN(2) PH_DRAIN(3)
-#undef PH_DRAIN
-#undef PH_NOP
-#undef PH_ESTEPS
-#undef PH_ESTEP
-#undef PH_STEP
-#undef PH_SB
-#undef PH_MFMA
-#undef PH_OPLOAD
-#undef PH_SLOT
-#undef PH_EL
-#undef PH_LOADALL
-#undef PH_LOADB
-#undef PH_LOADA
-#undef DSR
-        } else {
         int cur = 0;
         TileIter it;
         for (it.init(walk.first, walk.stride, ntx, nty); it.tile < walk.end; it.advance(walk.stride, ntx, nty)) {
@@ -694,7 +522,6 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             STAMP(t4);
             STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
         }
-        }   // !PIPE
     }
 #ifdef VSR_ABL
     if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) {
@@ -742,13 +569,13 @@ __global__ void sign_bits_c64_kernel(const bf16_t* __restrict__ x, uint2* __rest
     bits[gid] = make_uint2(out[0], out[1]);
 }
 
-template <int ACT, bool HAS_RES, int MASK, bool PIPE = false>
+template <int ACT, bool HAS_RES, int MASK>
 static int launch_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
-    auto kern = conv3x3_c64_persist_kernel<ACT, HAS_RES, MASK, PIPE>;
+    auto kern = conv3x3_c64_persist_kernel<ACT, HAS_RES, MASK>;
     static VsrDevOnce once;                                 // one per instantiation, remembered per device
     { const int rc = vsr_set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), P_LDS); if (rc != VSR_OK) return rc; }
     const int tiles = a.N * cdiv(a.W, PTW) * cdiv(a.H, PTH);
-    int gx = num_cus / (a.nz * (a.cu_div > 1 ? a.cu_div : 1));
+    int gx = num_cus / a.nz;
     gx &= ~7;                                               // whole XCD groups (xcd_tile_walk)
     if (gx < 8) gx = num_cus / a.nz;
     if (gx < 1) gx = 1;
@@ -774,13 +601,7 @@ extern "C" int vsr_debug_read_stamps(unsigned long long* host_out) {
 // Eligibility is decided by the dispatcher in conv_mfma.hip (bf16, 3x3, one 64-channel source at unit
 // step, 64 output channels, blocked pixel-major destination).  Returns VSR_ERR_UNSUPPORTED for an epilogue
 // combination that has no instantiation; the caller then uses the generic kernel.
-int vsr_launch_conv3x3_c64_wreg(const ConvArgs& a, int num_cus, hipStream_t st);      // conv3x3_wreg.hip (experiment)
-static int g_wreg_on = -1;        // -1: not decided yet (then VSRLAB_AMD_WREG through vsr_env()), 0 / 1
-extern "C" void vsr_debug_set_wreg(int on) { __atomic_store_n(&g_wreg_on, on ? 1 : 0, __ATOMIC_RELAXED); }
 int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t st) {
-    // the weights-in-registers experiment for the launches it supports: VSRLAB_AMD_WREG=1 at start-up, or vsr_debug_set_wreg() (A/B in one process)
-    if (__atomic_load_n(&g_wreg_on, __ATOMIC_RELAXED) < 0) __atomic_store_n(&g_wreg_on, vsr_env().wreg ? 1 : 0, __ATOMIC_RELAXED);
-    if (__atomic_load_n(&g_wreg_on, __ATOMIC_RELAXED) == 1) { const int rc = vsr_launch_conv3x3_c64_wreg(a, num_cus, st); if (rc != VSR_ERR_UNSUPPORTED) return rc; }
     bool res = false, aux = false;
     for (int z = 0; z < a.nz; ++z) { res = res || a.res[z]; aux = aux || a.aux[z]; }
     for (int z = 0; z < a.nz; ++z) if ((res && !a.res[z]) || (aux && !a.aux[z])) return VSR_ERR_UNSUPPORTED;
@@ -799,9 +620,7 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
         return VSR_ERR_UNSUPPORTED;                                                  // in-tile offsets are 32-bit
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
     PERSIST_CASE(ACT_RELU, false, MASK_NONE)     // conv1 of a ResidualConv
-    // conv2 + skip ; dgrad(conv1) + dX: the pipelined tile loop (VSRLAB_AMD_CONV_PIPE=1; off by default -- see the kernel) or the plain one
-    if (a.act == ACT_NONE && res && mask == MASK_NONE && vsr_env().conv_pipe) return launch_persist<ACT_NONE, true, MASK_NONE, true>(a, num_cus, st);
-    PERSIST_CASE(ACT_NONE, true, MASK_NONE)
+    PERSIST_CASE(ACT_NONE, true, MASK_NONE)      // conv2 + skip ; dgrad(conv1) + dX
     PERSIST_CASE(ACT_LEAKY, false, MASK_NONE)    // conv_last.0
     PERSIST_CASE(ACT_NONE, false, MASK_NONE)     // upsample phases, plain dgrads
     PERSIST_CASE(ACT_NONE, false, MASK_RELU)     // dgrad(conv2) * ReLU'

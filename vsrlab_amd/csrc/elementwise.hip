@@ -143,6 +143,12 @@ constexpr int GR = 5;                                   // search radius: source
 constexpr int GTH = 8, GTW = 32, GCAP = 8;
 constexpr int GHH = GTH + 2 * GR, GHW = GTW + 2 * GR;   // 18 x 42 sources per tile
 constexpr double FAR_FX = 17592186044416.0;             // 2^44: fixed-point unit of the far accumulator
+// A far contribution that the fixed-point accumulator cannot hold (a NaN / Inf cotangent, |g w| >= 2.5e5) must not turn into finite
+// garbage (the fp32 atomics this replaced propagated it, and FusedAdam's skip-on-non-finite-norm relies on that): the far kernel
+// sets this bit in the launch's far counter instead of adding, and the gather kernel then writes NaN to EVERY pixel of its output
+// (coarser than grid_sampler_2d_backward, which would poison the four destinations only; what matters downstream is that the
+// gradient norm is not finite).
+constexpr int FAR_BAD = 0x40000000;
 
 __device__ __forceinline__ bool flow_is_far(float fx, float fy) {
     return !(fabsf(fx) <= (float)(GR - 1) && fabsf(fy) <= (float)(GR - 1));      // NaN counts as far
@@ -197,7 +203,9 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const T* __restric
         hit_n[tid] = cnt;
     }
     __syncthreads();
-    const bool add_far = far_count[0] != 0;
+    const int far_n = far_count[0];
+    const bool add_far = far_n != 0;
+    const bool far_bad = (far_n & FAR_BAD) != 0;        // a far contribution was not representable (NaN / Inf / huge cotangent)
     const int c = tid & 7;
     for (int pass = 0; pass < 8; ++pass) {              // phase 2: 32 destination pixels per pass, 8 lanes (chunks) each
         const int d = pass * 32 + (tid >> 3);
@@ -237,6 +245,10 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const T* __restric
             long long* sp = S + (((long long)n * H + yi) * W + xi) * C + c * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { acc[j] += (float)((double)sp[j] * (1.0 / FAR_FX)); sp[j] = 0; }
+            if (far_bad) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_nanf("");
+            }
         }
         const long long o = img + pm_off(yi, xi, c, W, C);
         if (dtop) {
@@ -290,9 +302,12 @@ __global__ void warp_bwd_far_kernel(const T* __restrict__ dout, const float* __r
         for (int t = 0; t < 4; ++t) {
             const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
             const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
-            if (xi >= 0 && xi < W && yi >= 0 && yi < H)
-                atomicAdd(reinterpret_cast<unsigned long long*>(imgp + ((long long)yi * W + xi) * C + c),
-                          (unsigned long long)__double2ll_rn((double)(g * wgt) * FAR_FX));       // two's complement: signed sums
+            if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+                const float gw = g * wgt;
+                if (!(fabsf(gw) < 2.5e5f)) atomicOr(far_count, FAR_BAD);                          // NaN, Inf or beyond the fixed-point range
+                else atomicAdd(reinterpret_cast<unsigned long long*>(imgp + ((long long)yi * W + xi) * C + c),
+                               (unsigned long long)__double2ll_rn((double)gw * FAR_FX));       // two's complement: signed sums
+            }
         }
         }
     }
@@ -796,10 +811,10 @@ __global__ void pack_multi_kernel(const PackArgs a) {
 // whose arrival order is not).
 constexpr int CHARB_BLOCKS = 1024;
 __global__ void charbonnier_grad_kernel(const float* __restrict__ sr, const float* __restrict__ hr, float* __restrict__ dsr,
-                                        float* __restrict__ partial, long long n, float eps, float scale) {
+                                        float* __restrict__ partial, long long n, float eps, float scale, int vec) {
     __shared__ float red[4];
     float local = 0.f;
-    const long long n4 = n >> 2;
+    const long long n4 = vec ? n >> 2 : 0;
     const float4* s4 = reinterpret_cast<const float4*>(sr);
     const float4* h4 = reinterpret_cast<const float4*>(hr);
     float4* d4 = reinterpret_cast<float4*>(dsr);
@@ -813,7 +828,14 @@ __global__ void charbonnier_grad_kernel(const float* __restrict__ sr, const floa
         d = a.w - b.w; r = sqrtf(d * d + eps); local += r; o.w = scale * d / r;
         d4[i] = o;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {          // tail of a length that is not a multiple of 4
+    if (!vec) {                                                   // a pointer that is not 16-byte aligned (a view at an odd storage offset): scalar
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const float d = sr[i] - hr[i];
+            const float r = sqrtf(d * d + eps);
+            local += r;
+            dsr[i] = scale * d / r;
+        }
+    } else if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {   // tail of a length that is not a multiple of 4
         const long long i = (n4 << 2) + threadIdx.x;
         const float d = sr[i] - hr[i];
         const float r = sqrtf(d * d + eps);
@@ -1010,10 +1032,13 @@ int vsr_launch_pack_multi(const VsrPackDesc* descs, int n, hipStream_t st) {
 int vsr_charbonnier_scratch_floats_impl() { return CHARB_BLOCKS; }
 int vsr_launch_charbonnier_grad(const float* sr, const float* hr, float* dsr, float* loss_acc, float* scratch, long long n, float eps,
                                 hipStream_t st) {
-    if ((reinterpret_cast<uintptr_t>(sr) | reinterpret_cast<uintptr_t>(hr) | reinterpret_cast<uintptr_t>(dsr)) & 15) return VSR_ERR_BADARG;   // float4 access
+    if (!sr || !hr || !dsr || !loss_acc || !scratch || n < 1) return VSR_ERR_BADARG;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(sr) | reinterpret_cast<uintptr_t>(hr) | reinterpret_cast<uintptr_t>(dsr);
+    if (bits & 3) return VSR_ERR_BADARG;
+    const int vec = (bits & 15) == 0;                      // float4 access needs 16-byte alignment; otherwise the scalar loop (same values, another fixed order)
     const long long want = ((n >> 2) + 255) / 256;
     const int blocks = (int)(want < 1 ? 1 : (want > CHARB_BLOCKS ? CHARB_BLOCKS : want));
-    hipLaunchKernelGGL(charbonnier_grad_kernel, dim3(blocks), dim3(256), 0, st, sr, hr, dsr, scratch, n, eps, 1.0f / (float)n);
+    hipLaunchKernelGGL(charbonnier_grad_kernel, dim3(blocks), dim3(256), 0, st, sr, hr, dsr, scratch, n, eps, 1.0f / (float)n, vec);
     hipLaunchKernelGGL(charbonnier_sum_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, loss_acc);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;

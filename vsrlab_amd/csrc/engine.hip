@@ -241,14 +241,12 @@ struct Ctx {
     hipStream_t st;
     int dtype;
     int lane;                   // 0: the caller's stream, 1: the helper stream (selects per-stream scratch)
-    int cu_div = 1;             // ConvArgs::cu_div of this context's persistent launches (2 inside the two-chain regions)
     mutable std::vector<VsrPackDesc>* batch = nullptr;      // while set, pack() collects descriptors for ONE multi-tensor launch
     void* at(size_t off) const { return ws + off; }
     const float* fat(size_t off) const { return reinterpret_cast<const float*>(ws + off); }
 
     ConvArgs base(int N, int H, int W) const {
         ConvArgs a = {};
-        a.cu_div = cu_div;
         a.in_step = 1; a.Hs = H; a.Ws = W; a.N = N; a.H = H; a.W = W; a.nz = 1;
         a.out_step = 1; a.Hd = H; a.Wd = W; a.CD = C; a.cout_real = C; a.dst_nstride = pm_image_elems(H, W, C);
         for (int s = 0; s < VSR_MAX_SRC; ++s) a.src_nstride[s] = pm_image_elems(H, W, C);
@@ -466,7 +464,7 @@ int chain_launch(const Plan& p, const ChainArgs& a, hipStream_t st) {
 }
 int trunk_chain_forward(const Ctx& c, const Plan& p, int dir, int i) {
     ChainArgs a = {};
-    a.base = c.ws; a.sync = (unsigned*)c.at(p.chain_sync[dir]); a.N = p.n; a.H = p.h; a.W = p.w; a.nlayers = 2 * p.rb; a.cu_div = c.cu_div;
+    a.base = c.ws; a.sync = (unsigned*)c.at(p.chain_sync[dir]); a.N = p.n; a.H = p.h; a.W = p.w; a.nlayers = 2 * p.rb;
     for (int b = 0; b < p.rb; ++b) {
         ChainLayer& l1 = a.layer[2 * b];
         l1 = {chain_off(p.xoff(dir, i, b)), chain_off(p.aoff(dir, i, b)), 0xffffffffu, 0xffffffffu, chain_off(p.sboff(dir, i, b)),
@@ -480,7 +478,7 @@ int trunk_chain_forward(const Ctx& c, const Plan& p, int dir, int i) {
 // dA_b = dgrad(conv2)(dX_{b+1}) * ReLU'(A_b), dX_b = dX_{b+1} + dgrad(conv1)(dA_b) for b = rb-1 .. 1, and dA_0: 2 rb - 1 layers
 int trunk_chain_backward(const Ctx& c, const Plan& p, int dir, int i) {
     ChainArgs a = {};
-    a.base = c.ws; a.sync = (unsigned*)c.at(p.chain_sync[dir]); a.N = p.n; a.H = p.h; a.W = p.w; a.cu_div = c.cu_div;
+    a.base = c.ws; a.sync = (unsigned*)c.at(p.chain_sync[dir]); a.N = p.n; a.H = p.h; a.W = p.w;
     int L = 0;
     for (int b = p.rb - 1; b >= 0; --b) {
         a.layer[L++] = {chain_off(p.dxoff(dir, i, b + 1)), chain_off(p.g1off(dir, i, b)), 0xffffffffu, chain_off(p.sboff(dir, i, b)), 0xffffffffu,
@@ -615,7 +613,7 @@ int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float
         // (chain launches spin on each other's tiles: two of them side by side could each hold the CUs the other's unstarted
         // workgroups need -- conv3x3_chain.hip, "Work distribution" -- so with the chains on, both directions share the caller's stream)
         CK(f.begin(!chain_on(p)));
-        const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
+        const Ctx c0{p, ws, st, p.dtype, 0}, c1{p, ws, f.side(), p.dtype, 1};
         CK(forward_chain(c0, p, 0, lrs));
         CK(forward_chain(c1, p, 1, lrs));
         CK(f.end());
@@ -907,7 +905,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
     CK(f.begin(!(chain_on(p) && !p.diet)));          // (diet: no chain launches in the backward, the two directions keep their two streams)
-    const Ctx c0{p, ws, st, p.dtype, 0, vsr_env().chain_share}, c1{p, ws, f.side(), p.dtype, 1, vsr_env().chain_share};
+    const Ctx c0{p, ws, st, p.dtype, 0}, c1{p, ws, f.side(), p.dtype, 1};
     CK(backward_chain(c0, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
     CK(f.end());
@@ -1287,6 +1285,14 @@ int vsr_flow_warp_bwd_ex(int dtype, const void* dout_pm, const float* flow, floa
     if (bad_dtype(dtype) || !dout_pm || !flow || !dacc || bad_dims(N, H, W) || Cc < 16 || (Cc & 15) || (padding_mode & ~1)) return VSR_ERR_BADARG;
     return vsr_launch_warp_bwd(dtype, dout_pm, flow, dacc, N, H, W, Cc, (long long)2 * H * W, (hipStream_t)stream, padding_mode);
 }
+// Test hook (not in the header): the engine's GATHER form of the 64-channel zeros-padding warp adjoint on its own -- out = T(dtop + adjoint(dout)),
+// near sources gathered, far ones through the 64-bit fixed-point accumulator S (N*H*W*64 long longs, all zero on entry and exit;
+// far_count: one zeroed int).  tests: against the scatter form above, and that a non-finite far contribution stays non-finite.
+extern "C" int vsr_debug_warp_bwd_gather(int dtype, const void* dout_pm, const float* flow, const void* dtop_pm, long long* S, int* far_count,
+                                         void* out_pm, int N, int H, int W, void* stream) {
+    if (bad_dtype(dtype) || !dout_pm || !flow || !S || !far_count || !out_pm || bad_dims(N, H, W)) return VSR_ERR_BADARG;
+    return vsr_launch_warp_bwd_gather(dtype, dout_pm, flow, dtop_pm, S, far_count, out_pm, N, H, W, (long long)2 * H * W, (hipStream_t)stream);
+}
 int vsr_flow_warp_bwd_flow_ex(int dtype, const void* in_pm, const void* dout_pm, const float* flow, float* dflow, int N, int H, int W,
                               int Cc, int padding_mode, void* stream) {
     if (bad_dtype(dtype) || !in_pm || !dout_pm || !flow || !dflow || bad_dims(N, H, W) || Cc < 16 || (Cc & 15) || (padding_mode & ~1)) return VSR_ERR_BADARG;
@@ -1340,7 +1346,7 @@ int vsr_conv3x3_c64_chain_fwd(const void* images, const void* wpack, const float
         return true;
     };
     ChainArgs a = {};
-    a.base = (char*)lo; a.sync = (unsigned*)sync; a.N = N; a.H = H; a.W = W; a.nlayers = nlayers; a.cu_div = 1;
+    a.base = (char*)lo; a.sync = (unsigned*)sync; a.N = N; a.H = H; a.W = W; a.nlayers = nlayers;
     for (int l = 0; l < nlayers; ++l) {
         ChainLayer& L = a.layer[l];
         L = {0, 0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, (l & 1) ? CHAIN_SKIP : CHAIN_RELU};

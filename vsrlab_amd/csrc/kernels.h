@@ -18,7 +18,6 @@ struct ChainArgs {
     char* base;
     unsigned* sync;              // vsr_chain_sync_bytes(): work counter, error word, one flag word per (layer, tile, MFMA wave); zeroed by the launcher
     int N, H, W, nlayers;
-    int cu_div;
     ChainLayer layer[VSR_CHAIN_MAX_LAYERS];
 };
 size_t vsr_chain_sync_bytes(int nlayers, int N, int H, int W);

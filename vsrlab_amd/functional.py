@@ -164,11 +164,28 @@ def conv3x3_c64(x_pm: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
 
 def chain_timeouts() -> int:
     """Dependency waits the trunk-chain kernel (csrc/conv3x3_chain.hip) has given up since the library was loaded (1 s each).
-    Anything but 0 means some launch ran on unfinished inputs: its results are void.  Synchronises the device."""
+    Anything but 0 means some launch ran on unfinished inputs.  Such a launch poisons its own output with NaN on the device
+    (chain_poison_kernel: sr, the loss and the gradient norm go non-finite, FusedAdam skips the step), so the counter is for
+    diagnosis.  Synchronises the device."""
     import ctypes
     out = ctypes.c_uint(0)
     _lib.check(_lib.load().vsr_debug_chain_timeouts(ctypes.byref(out)), "debug_chain_timeouts")
     return int(out.value)
+
+
+_chain_timeouts_seen = 0
+
+
+def raise_on_chain_timeout(where: str = "") -> None:
+    """For the places of a training loop that synchronise anyway (reading the loss, a checkpoint, `rewind_skipped_step`):
+    raise if a chain launch has given up a dependency wait since the last call.  The launch concerned has already turned its
+    outputs into NaN; this names the cause (a long foreign kernel, a debugger or another process holding the GPU's CUs)."""
+    global _chain_timeouts_seen
+    n = chain_timeouts()
+    if n != _chain_timeouts_seen:
+        new, _chain_timeouts_seen = n - _chain_timeouts_seen, n
+        raise RuntimeError(f"vsrlab_amd: {new} dependency wait(s) of the trunk-chain kernel timed out{' (' + where + ')' if where else ''}: "
+                           "the affected launches wrote NaN into their outputs; VSRLAB_AMD_CHAIN=0 runs one launch per layer")
 
 
 class ResidualChainC64:

@@ -147,11 +147,22 @@ class FusedAdam(torch.optim.Optimizer):
     def rewind_skipped_step(self):
         """If the last ``step()`` was skipped on the device (non-finite gradient norm), take its count back so that the step
         count matches what ``GradScaler.step`` + ``torch.optim.Adam`` would hold.  Synchronises (reads ``last_grad_norm``)."""
-        if self._step > 0 and not bool(torch.isfinite(self.last_grad_norm).item()):
+        skipped = self._step > 0 and not bool(torch.isfinite(self.last_grad_norm).item())
+        if skipped:
+            from .functional import raise_on_chain_timeout
+            raise_on_chain_timeout("FusedAdam skipped a step on a non-finite gradient norm")      # (synchronised already)
+        if skipped:
             self._step -= 1
             self._step_t.fill_(float(self._step))
             return True
         return False
+
+    def state_dict(self):
+        """``torch.optim.Adam``'s layout.  A checkpoint is a host-side event: it also checks that no trunk-chain launch gave up a
+        dependency wait since the last check (functional.raise_on_chain_timeout)."""
+        from .functional import raise_on_chain_timeout
+        raise_on_chain_timeout("FusedAdam.state_dict")
+        return super().state_dict()
 
     # checkpoints: torch.optim.Adam's layout in, flat buffers refreshed --------------------------- #
     def load_state_dict(self, state_dict):
