@@ -198,12 +198,17 @@ struct Plan {
                 if (diet) {
                     G1[dir].assign(2, 0); DX[dir].assign(2, 0);
                     for (int k = 0; k < 2; ++k) { G1[dir][k] = b.take(a1); DX[dir][k] = b.take(a1); }
-                } else {
+                } else if (dir == 0) {
                     G1[dir].assign((size_t)t * rb, 0); DX[dir].assign((size_t)t * (rb + 1), 0);
                     for (int i = 0; i < t; ++i) {
                         for (int k = 0; k < rb; ++k) G1[dir][(size_t)i * rb + k] = b.take(a1);
                         for (int k = 1; k <= rb; ++k) DX[dir][(size_t)i * (rb + 1) + k] = b.take(a1);
                     }
+                } else {
+                    // ONE set of trunk activation gradients for both directions (r04: 2 x 7 x 60 x 66.8 MB = 56 GB at config 2 before):
+                    // a direction's gradients are dead once its all-frames weight-gradient launches have read them, and
+                    // backward_impl runs direction 1 (data gradients, then weight gradients) and then direction 0 on ONE stream
+                    G1[dir] = G1[0]; DX[dir] = DX[0];
                 }
             }
             dFeatB.assign(t, 0); dFF.assign(t, 0);
@@ -904,7 +909,9 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st));
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
-    CK(f.begin(!(chain_on(p) && !p.diet)));          // (diet: no chain launches in the backward, the two directions keep their two streams)
+    // One stream: the two directions share their activation-gradient buffers (Plan::build), and chain launches of two streams could
+    // each hold the CUs the other's unstarted workgroups need (conv3x3_chain.hip).  diet: rings per direction, no chains: two streams.
+    CK(f.begin(p.diet));
     const Ctx c0{p, ws, st, p.dtype, 0}, c1{p, ws, f.side(), p.dtype, 1};
     CK(backward_chain(c0, p, 1, lrs, g));
     CK(backward_chain(c1, p, 0, lrs, g));
