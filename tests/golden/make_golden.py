@@ -206,6 +206,28 @@ def lrgrad():
     print("basicvsr_m64_rb3_lrgrad", {k: v.shape for k, v in out.items()})
 
 
+def up2():
+    """BasicVSR with upscale = 2 (the constructor is generic, basicvsr.py:12-23: upscale // 2 = ONE PixelShufflePack, conv_last at
+    2h x 2w, `nn.Upsample(scale_factor=2)` skip; conf/train/model/basicvsr.yaml:4 takes the scale from the dataset config), float64:
+    sr, every trainable gradient of mean(sr * cot), and the gradient w.r.t. the clip (the x2 bilinear adjoint among others)."""
+    torch.set_num_threads(8)
+    basicvsr, spynet, realbasicvsr, conv, upsampling = import_reference()
+    mid, blocks, shape = 64, 3, (2, 3, 3, 24, 40)
+    m = load_keyed(basicvsr.BasicVSR(mid, blocks, 2, False, False)).double()
+    lrs = rand(10, *shape).double().requires_grad_(True)
+    n, t, _, h, w = shape
+    sr = m(lrs)
+    cot = rand(13, n, t, 3, 2 * h, 2 * w, lo=-1, hi=1).double()
+    torch.mean(sr * cot).backward()
+    out = {"sr": sr.detach().numpy().astype(np.float32), "grad_lrs": lrs.grad.detach().numpy().astype(np.float64),
+           "seed_lr": np.asarray(10), "seed_cot": np.asarray(13)}
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            out["grad__" + k.replace(".", "__")] = prm.grad.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "basicvsr_m64_rb3_up2.npz"), **out)
+    print("basicvsr_m64_rb3_up2", len(out), "arrays; sr", out["sr"].shape)
+
+
 def realtrain():
     """RealBasicVSR training gradients.  The reference's own backward raises in fp32 (`x += residues` overwrites a tensor
     saved for backward, realbasicvsr.py:29); it runs under autocast, where the saved tensors are
@@ -503,3 +525,5 @@ if __name__ == "__main__":
         trainflow()
     if which in ("all", "lrgrad"):
         lrgrad()
+    if which in ("all", "up2"):
+        up2()

@@ -4,6 +4,8 @@ fp64 outputs (tests/golden/unet_discriminator.npz, gan_step.npz) and the CPU ora
 
 Tolerances: fp32 build 1e-3 relative (north-star bar); bf16 build: error <= 1.5 x the error of the oracle that rounds to
 bf16 at the same storage points (the noise-floor criterion of test_hip_parity.py)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -62,6 +64,48 @@ def test_spectral_norm_kernel_forward_backward():
                 wn0, _, _, _ = D.spectral_normalize(w.double(), u.double(), v.double(), False)
                 assert torch.equal(ud.cpu(), u) and torch.equal(vd.cpu(), v)           # eval: buffers untouched
                 assert rel_err(out.cpu(), wn0) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_spectral_conv_standalone_vs_torch(dtype):
+    """SpectralConv(64, 64) on its own (core/modules/conv.py:6-13; round-3 VERDICT missing #3) against the reference's definition
+    itself -- torch.nn.utils.spectral_norm(nn.Conv2d(64, 64, 3, 1, 1, bias=False)) on the CPU in float64 -- over two training-mode
+    forwards (the buffers move) and one eval forward: output, d/dx, d/d weight_orig, weight_u / weight_v."""
+    dev = _gpu()
+    import torch.nn as nn
+    from torch.nn.utils import spectral_norm
+    from vsrlab_amd.core.modules.conv import SpectralConv
+    torch.manual_seed(3)
+    ref = spectral_norm(nn.Conv2d(64, 64, 3, 1, 1, bias=False)).double()
+    m = SpectralConv(64, 64)
+    with torch.no_grad():
+        m.conv.weight_orig.copy_(ref.weight_orig.float())
+        m.conv.weight_u.copy_(ref.weight_u.float())
+        m.conv.weight_v.copy_(ref.weight_v.float())
+    m = m.to(dev)
+    os.environ["VSRLAB_AMD_DTYPE"] = dtype
+    t_out, t_g = (1e-3, 1e-3) if dtype == "fp32" else (2e-2, 3e-2)
+    try:
+        for step, training in enumerate((True, True, False)):
+            ref.train(training)
+            m.train(training)
+            x = rand(60 + step, 2, 64, 21, 40, lo=-1, hi=1)
+            cot = rand(70 + step, 2, 64, 21, 40, lo=-1, hi=1)
+            xr = x.double().requires_grad_(True)
+            ref.weight_orig.grad = None
+            yr = ref(xr)                                     # ONE call per step: a training-mode forward moves the buffers
+            (yr * cot.double()).sum().backward()
+            xd = x.to(dev).requires_grad_(True)
+            m.conv.weight_orig.grad = None
+            y = m(xd)
+            (y * cot.to(dev)).sum().backward()
+            assert rel_err(y, yr) < t_out, (step, rel_err(y, yr))
+            assert rel_l2(xd.grad, xr.grad) < t_g and rel_l2(m.conv.weight_orig.grad, ref.weight_orig.grad) < t_g, step
+            assert rel_err(m.conv.weight_u, ref.weight_u) < 1e-4 and rel_err(m.conv.weight_v, ref.weight_v) < 1e-4, step
+    finally:
+        del os.environ["VSRLAB_AMD_DTYPE"]
+    with pytest.raises(NotImplementedError):
+        SpectralConv(64, 128, 4, 2, 1).to(dev)(rand(1, 1, 64, 16, 16).to(dev))
 
 
 def test_bce_with_logits_and_adversarial_loss():

@@ -133,8 +133,12 @@ def test_workspace_query_and_unsupported_configs_fail_loudly():
         assert full_b <= 112 * 2 ** 30, (mode, full_b / 2 ** 30)
     assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(diet), 0) == infer
     assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(_lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 4, 1, 2)), 1) == 0
-    for bad in (_lib.BasicVSRDesc(1, 7, 540, 960, 32, 30, 4, 1), _lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 2, 1),
-                _lib.BasicVSRDesc(1, 7, 540, 960, 64, 0, 4, 1)):
+    # upscale 2 (one PixelShufflePack: basicvsr.py:19) is supported since round 4: two tensors fewer, a smaller arena
+    up2 = _lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 2, _lib.DT_BF16)
+    assert lib.vsr_basicvsr_num_params(ctypes.byref(up2)) == 314
+    assert 0 < lib.vsr_basicvsr_workspace_bytes(ctypes.byref(up2), 1) < train
+    for bad in (_lib.BasicVSRDesc(1, 7, 540, 960, 32, 30, 4, 1), _lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 3, 1),
+                _lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 8, 1), _lib.BasicVSRDesc(1, 7, 540, 960, 64, 0, 4, 1)):
         assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(bad), 1) == 0
 
 

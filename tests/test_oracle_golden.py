@@ -87,6 +87,32 @@ def test_basicvsr_end_to_end_fwd_bwd(tag, mid, blocks, shape):
     assert not any("spynet" in k for k in grads)       # frozen flow net: basicvsr.py:25-28
 
 
+def test_basicvsr_upscale_2_vs_reference():
+    """BasicVSR(64, 3, upscale=2) (basicvsr.py:12-23 is generic: ONE PixelShufflePack, conv_last at 2h x 2w, x2 bilinear skip;
+    conf/train/model/basicvsr.yaml:4 takes the scale from the dataset config): the oracle against the reference's float64 run --
+    sr, all 36 trainable gradients, and the gradient w.r.t. the clip (the x2 bilinear adjoint among others)."""
+    g = golden("basicvsr_m64_rb3_up2")
+    shape = (2, 3, 3, 24, 40)
+    n, t, _, h, w = shape
+    sd = {k: v.double() for k, v in O.keyed_state_dict(O.basicvsr_param_shapes(64, 3, 2)).items()}
+    assert O.count_upsample(sd) == 1
+    leaves = {k: v.clone().requires_grad_("spynet" not in k) for k, v in sd.items()}
+    lrs = rand(g["seed_lr"], *shape).double().requires_grad_(True)
+    cot = rand(g["seed_cot"], n, t, 3, 2 * h, 2 * w, lo=-1, hi=1).double()
+    sr = O.basicvsr_forward(leaves, lrs)
+    assert tuple(sr.shape) == (n, t, 3, 2 * h, 2 * w)
+    torch.mean(sr * cot).backward()
+    assert rel_err(sr, g["sr"]) < TOL
+    assert rel_err(lrs.grad, g["grad_lrs"]) < 1e-6
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            name = k[len("grad__"):].replace("__", ".")
+            assert rel_err(leaves[name].grad, v) < 1e-5, name          # (stored as float32)
+            checked += 1
+    assert checked == 36
+
+
 def test_basicvsr_train_flow_spynet_grads():
     """train_flow=True (conf/experiment/basic.yaml:7): all 60 SPyNet gradients of the oracle against the reference's,
     float64 on both sides; 7 tensors in full, every tensor through (sum, L2 norm, seeded projection)."""

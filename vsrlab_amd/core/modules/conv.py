@@ -31,15 +31,21 @@ class _SpectralConv2d(nn.Module):
 
 class SpectralConv(nn.Module):
     """spectral_norm(Conv2d(in_ch, out_ch, ks, stride, pad, bias=False))  (conv.py:6-13).  A building block of
-    ``UNetDiscriminator``, which runs all of its layers in one engine call."""
+    ``UNetDiscriminator``, which runs all of its layers in one engine call; called on its own it is an ordinary differentiable
+    module for the shape the per-layer kernels serve (64 -> 64, 3x3, stride 1, padding 1 = the class defaults at 64 channels):
+    ``vsr_spectral_norm`` (one power iteration per training-mode forward, ``weight_u`` / ``weight_v`` updated in place) +
+    ``vsr_conv_layer_fwd`` / ``_bwd``."""
 
     def __init__(self, in_ch, out_ch, ks=3, stride=1, pad=1):
         super().__init__()
         self.conv = _SpectralConv2d(in_ch, out_ch, ks, stride, pad)
 
     def forward(self, x):
-        raise NotImplementedError("SpectralConv runs inside the UNetDiscriminator engine (vsr_disc_forward); "
-                                  "standalone use is not on the HIP path")
+        c = self.conv
+        if (c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding) != (64, 64, 3, 1, 1):
+            raise NotImplementedError("standalone HIP SpectralConv: Conv2d(64, 64, 3, 1, 1); the wide and the 4x4 stride-2 layers run "
+                                      "inside the UNetDiscriminator engine (vsr_disc_forward)")
+        return VF.spectral_conv_forward(x, c.weight_orig, c.weight_u, c.weight_v, self.training)
 
 
 class ConvReLU(nn.Module):

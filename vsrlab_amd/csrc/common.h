@@ -64,11 +64,11 @@ struct ConvArgs {
     const void* aux[VSR_MAX_Z];          // optional activation-mask source, destination layout, type T
     int mask_mode;
     // EPI_PLANAR: fp32 planar destination [N][cout_real][Hd][Wd] (+ optional planar residual,
-    // + optional bilinear x4 of a planar LR frame: basicvsr.py:22,82)
+    // + optional bilinear x base_scale (4, or 2 for upscale = 2; 0 = 4) of a planar LR frame: basicvsr.py:22,82)
     const float* pres;
     const float* base_lr;
     long long base_nstride;
-    int base_h, base_w;
+    int base_h, base_w, base_scale;
     // Sign bits of a ReLU output, 1 bit per element, in the persistent kernel's own tile order ([tile][wave][lane] x
     // 8 bytes): written by the bias+ReLU launch (sign_out), read by the masked data-gradient launch of the same
     // tensor shape (sign_bits) INSTEAD of re-reading the bf16 activation `aux` (66 MB -> 4 MB at 540p).  Other kernels

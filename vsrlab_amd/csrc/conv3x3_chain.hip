@@ -61,7 +61,10 @@ constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11;
 // reads after step 0 (bare MFMA loop); bit 6: the producers issue only their first tile (no DMA); bit 7: no output stores; bit 11: every fragment read
 // of a tile re-reads the first K step's addresses (the LDS reads stay, the operands stop changing); bit 12: epilogue = convert + store; bit 13 / 14: no A (weight) / no B (pixel)
 // fragment reads after the first K step (what weights held in registers would save); bit 15: the weight image in LDS in MFMA-fragment
-// order (every A read = 1 KiB contiguous) instead of [cout row][8 swizzled chunks] -- same results, an energy experiment.  On the
+// order (every A read = 1 KiB contiguous) instead of [cout row][8 swizzled chunks] -- same results, an energy experiment; bit 16: no A
+// (weight) fragment reads for the taps of kernel row ky = 1 (the upper bound of what holding that row's 24 fragments = 96 registers
+// per lane in registers would save: round-3 VERDICT next #1a); bit 17: only the first 8 of the 18 K steps = 128 of 288 MFMAs and
+// 64 of 144 fragment reads per tile and wave (the matrix work of a Winograd F(2x2, 3x3) kernel WITHOUT its transforms: VERDICT #1c).  On the
 // back-to-back leg the kernel's time is its energy, so these price the energy of LDS reads / DMA / stores.
 #ifdef VSR_ABL
 #define CABL(bit) ((VSR_ABL >> (bit)) & 1)
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 bf16x8_t fa[2][4], fb[2][4];
                 const unsigned bb = (unsigned)(W_BYTES + cur * IN_BYTES + b_lane);
 #define DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
-#define CV_LOADA(tap_, kk_, slot, mb) if (!((CABL(5) || CABL(13)) && tap_ + kk_ > 0)) DSR(fa[slot][mb], (CABL(11) ? a_lo[0] : (tap_ < 6 ? a_lo[kk_] : a_hi[kk_])), (CABL(11) ? 0 : (tap_ < 6 ? tap_ : tap_ - 6) * 8192) + (mb) * (CABL(15) ? 1024 : 2048));
+#define CV_LOADA(tap_, kk_, slot, mb) if (!((CABL(5) || CABL(13)) && tap_ + kk_ > 0) && !(CABL(16) && tap_ >= 3 && tap_ <= 5)) DSR(fa[slot][mb], (CABL(11) ? a_lo[0] : (tap_ < 6 ? a_lo[kk_] : a_hi[kk_])), (CABL(11) ? 0 : (tap_ < 6 ? tap_ : tap_ - 6) * 8192) + (mb) * (CABL(15) ? 1024 : 2048));
 #define CV_LOADB(ky_, kx_, kk_, slot, nb) if (!((CABL(5) || CABL(14)) && ky_ + kx_ + kk_ > 0)) DSR(fb[slot][nb], bb, CABL(11) ? (((nb) >> 1)) * (PTWH * 128) + (((nb) & 1) * 16) * 16 : (((nb) >> 1) + ky_) * (PTWH * 128) + kk_ * (4 * PTWH * 16) + (((nb) & 1) * 16 + kx_) * 16);
 #define CV_LOAD(s, slot)                                                                                               \
                 {                                                                                                      \
@@ -478,8 +481,11 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 CV_LOAD(0, 0)
-                CV_STEP(0) CV_STEP(1) CV_STEP(2) CV_STEP(3) CV_STEP(4) CV_STEP(5) CV_STEP(6) CV_STEP(7) CV_STEP(8)
+                CV_STEP(0) CV_STEP(1) CV_STEP(2) CV_STEP(3) CV_STEP(4) CV_STEP(5) CV_STEP(6) CV_STEP(7)
+                if (!CABL(17)) {
+                CV_STEP(8)
                 CV_STEP(9) CV_STEP(10) CV_STEP(11) CV_STEP(12) CV_STEP(13) CV_STEP(14) CV_STEP(15) CV_STEP(16) CV_STEP(17)
+                }
 #undef CV_ML_A
 #undef CV_ML_B
 #undef CV_STEP

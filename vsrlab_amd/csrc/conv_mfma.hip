@@ -96,9 +96,9 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     return v;
 }
 
-// PyTorch upsample_bilinear2d(align_corners=False) source index for scale 1/4 (basicvsr.py:22)
-__device__ __forceinline__ void bil4(int d, int in_size, int& i0, int& i1, float& l1) {
-    float s = (d + 0.5f) * 0.25f - 0.5f;
+// PyTorch upsample_bilinear2d(align_corners=False) source index for scale `inv` = 1/4 (or 1/2: upscale = 2) (basicvsr.py:22)
+__device__ __forceinline__ void bil4(int d, int in_size, int& i0, int& i1, float& l1, float inv) {
+    float s = (d + 0.5f) * inv - 0.5f;
     s = s < 0.f ? 0.f : s;
     i0 = (int)s;
     i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs a) {
                 const long long plane = (long long)a.Hd * a.Wd;
                 float* dst = reinterpret_cast<float*>(a.dst[z]) + (long long)n * a.dst_nstride + (long long)oy * a.Wd + ox;
                 int y0 = 0, y1 = 0, x0 = 0, x1 = 0; float ly = 0.f, lx = 0.f;
-                if (a.base_lr) { bil4(oy, a.base_h, y0, y1, ly); bil4(ox, a.base_w, x0, x1, lx); }
+                if (a.base_lr) { const float binv = a.base_scale == 2 ? 0.5f : 0.25f; bil4(oy, a.base_h, y0, y1, ly, binv); bil4(ox, a.base_w, x0, x1, lx, binv); }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (c >= a.cout_real) break;

@@ -719,40 +719,43 @@ __global__ void resize_norm_bwd_kernel(const float* __restrict__ dnorm, float* _
     }
 }
 
-// dlr (F,3,h,w) = bilinear_x4^T(dsr (F,3,4h,4w))   (the `+ upscale(lr_i)` skip, basicvsr.py:22,82), as a gather: LR pixel
-// y receives from the HR rows whose two source rows (align_corners=False, clamped at 0) include y
-__global__ void bilinear4_bwd_kernel(const float* __restrict__ dsr, float* __restrict__ dlr, long long planes, int h, int w) {
+// dlr (F,3,h,w) = bilinear_xS^T(dsr (F,3,S h,S w)), S = 4 or 2 (the `+ upscale(lr_i)` skip, basicvsr.py:22,82), as a gather: LR
+// pixel y receives from the HR rows whose two source rows (align_corners=False, clamped at 0) include y: rows S y - S .. S y + 2 S - 1
+template <int S>
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dsr, float* __restrict__ dlr, long long planes, int h, int w) {
     const long long total = planes * h * w;
-    const int H = 4 * h, W = 4 * w;
+    const int H = S * h, W = S * w;
+    constexpr int K = 3 * S;
+    constexpr float INV = 1.f / (float)S;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % w);
         const int y = (int)((idx / w) % h);
         const long long pl = idx / ((long long)w * h);
         const float* sp = dsr + pl * H * W;
-        float wy[12], wx[12];
-        int Y0 = 4 * y - 4, X0 = 4 * x - 4;
+        float wy[K], wx[K];
+        int Y0 = S * y - S, X0 = S * x - S;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < K; ++k) {
             const int Y = Y0 + k, X = X0 + k;
             wy[k] = 0.f; wx[k] = 0.f;
             if (Y >= 0 && Y < H) {
-                float s = (Y + 0.5f) * 0.25f - 0.5f; s = s < 0.f ? 0.f : s;
+                float s = (Y + 0.5f) * INV - 0.5f; s = s < 0.f ? 0.f : s;
                 const int i0 = (int)s; const int i1 = i0 + (i0 < h - 1 ? 1 : 0); const float l1 = s - (float)i0;
                 wy[k] = (i0 == y ? 1.f - l1 : 0.f) + (i1 == y ? l1 : 0.f);
             }
             if (X >= 0 && X < W) {
-                float s = (X + 0.5f) * 0.25f - 0.5f; s = s < 0.f ? 0.f : s;
+                float s = (X + 0.5f) * INV - 0.5f; s = s < 0.f ? 0.f : s;
                 const int i0 = (int)s; const int i1 = i0 + (i0 < w - 1 ? 1 : 0); const float l1 = s - (float)i0;
                 wx[k] = (i0 == x ? 1.f - l1 : 0.f) + (i1 == x ? l1 : 0.f);
             }
         }
         float acc = 0.f;
-        for (int ky = 0; ky < 12; ++ky) {
+        for (int ky = 0; ky < K; ++ky) {
             if (wy[ky] == 0.f) continue;
             const float* row = sp + (long long)(Y0 + ky) * W;
             float r = 0.f;
 #pragma unroll
-            for (int kx = 0; kx < 12; ++kx)
+            for (int kx = 0; kx < K; ++kx)
                 if (wx[kx] != 0.f) r += wx[kx] * row[X0 + kx];
             acc += wy[ky] * r;
         }
@@ -992,8 +995,9 @@ int vsr_launch_resize_norm_bwd(const float* dnorm, float* dframes, const float* 
     return VSR_OK;
 }
 
-int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int h, int w, hipStream_t st) {
-    hipLaunchKernelGGL(bilinear4_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, st, dsr, dlr, planes, h, w);
+int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int h, int w, hipStream_t st, int scale) {
+    if (scale == 2) hipLaunchKernelGGL(bilinear_bwd_kernel<2>, dim3(grid_for(planes * h * w)), dim3(256), 0, st, dsr, dlr, planes, h, w);
+    else hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid_for(planes * h * w)), dim3(256), 0, st, dsr, dlr, planes, h, w);
     HIP_CHECK_RET(hipGetLastError());
     return VSR_OK;
 }

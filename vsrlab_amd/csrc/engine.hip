@@ -88,6 +88,7 @@ struct Plan {
     bool bwd, flowgrad;          // flowgrad: train_flow (basicvsr.py:25-28), SPyNet is differentiated too
     bool diet;                   // VsrBasicVSRDesc.arena_mode = 1 (training only): see vsrlab_hip.h
     int rb, n, t, h, w, dtype;
+    int scale, ups;              // upscale (2 or 4, basicvsr.py:12-23) and its PixelShufflePack count scale / 2
     size_t es;
     size_t px1;                 // elements of one blocked (n,h,w,64) tensor
     size_t s_elems;             // elements of the plain 64-bit fixed-point warp-scatter accumulator (n,h,w,64)
@@ -135,12 +136,14 @@ struct Plan {
         if (d.arena_mode != 0 && d.arena_mode != 1) return VSR_ERR_BADARG;
         diet = bwd && d.arena_mode == 1;
         rb = d.res_blocks; n = d.n; t = d.t; h = d.h; w = d.w; dtype = d.dtype;
-        if (d.mid_channels != C || d.upscale != 4 || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
+        scale = d.upscale; ups = scale / 2;
+        if (d.mid_channels != C || (scale != 4 && scale != 2) || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
         if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
         es = esize(dtype);
         px1 = (size_t)n * pm_image_elems(h, w, C);
         s_elems = (size_t)n * h * w * C;
-        const size_t a2 = (size_t)n * pm_image_elems(2 * h, 2 * w, C) * es, a4 = (size_t)n * pm_image_elems(4 * h, 4 * w, C) * es;
+        // a2: a blocked 64-channel tensor at 2h x 2w; a4: at the output size scale h x scale w (= a2 for upscale 2, which has no U1)
+        const size_t a2 = (size_t)n * pm_image_elems(2 * h, 2 * w, C) * es, a4 = (size_t)n * pm_image_elems(scale * h, scale * w, C) * es;
         Bump b;
         const size_t w64 = (size_t)9 * C * C * es;
         for (int dir = 0; dir < 2; ++dir) {
@@ -182,13 +185,13 @@ struct Plan {
         // buffer each, recomputed from Pt[i] at the top of the frame's reconstruction backward (2.4 GB per frame at 540p x4)
         for (int i = 0; i < nrec; ++i) {
             Pt[i] = b.take(a1);
-            if (diet && i > 0) { U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; } else { U0[i] = b.take(a2); U1[i] = b.take(a4); C0[i] = b.take(a4); }
+            if (diet && i > 0) { U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; } else { U0[i] = b.take(a2); U1[i] = ups == 2 ? b.take(a4) : U0[i]; C0[i] = b.take(a4); }
         }
         for (int i = nrec; i < t; ++i) { Pt[i] = Pt[0]; U0[i] = U0[0]; U1[i] = U1[0]; C0[i] = C0[0]; }
         SBC0.assign(t, 0); SBPt.assign(t, 0);
         if (bwd && dtype == VSR_BF16)
             for (int i = 0; i < t; ++i) {
-                SBC0[i] = b.take((size_t)n * cdiv(4 * h, 8) * cdiv(4 * w, 32) * 2048);
+                SBC0[i] = b.take((size_t)n * cdiv(scale * h, 8) * cdiv(scale * w, 32) * 2048);
                 SBPt[i] = b.take((size_t)n * cdiv(h, 8) * cdiv(w, 32) * 2048);
             }
         if (bwd) {
@@ -217,7 +220,9 @@ struct Plan {
             far_cnt = b.take((size_t)2 * 32 * 4);
             G_C0 = b.take(a4); G_P = b.take(a1);
             // diet: dU1 is written after C0's last use and dU0 after U1's (recon_backward): they take those buffers
-            if (diet) { G_U1 = C0[0]; G_U0 = U1[0]; } else { G_U1 = b.take(a4); G_U0 = b.take(a2); }
+            // (upscale 2: there is no U1 / dU1; dU0 is conv_last.0's data gradient and takes C0's buffer in the diet arena)
+            if (ups == 2) { if (diet) { G_U1 = C0[0]; G_U0 = U1[0]; } else { G_U1 = b.take(a4); G_U0 = b.take(a2); } }
+            else { G_U0 = diet ? C0[0] : b.take(a2); G_U1 = G_U0; }
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
@@ -321,6 +326,7 @@ struct Ctx {
 // parameter index helpers (order documented in vsrlab_hip.h)
 struct PIdx {
     int rb;
+    int ups = 2;                 // PixelShufflePack count = upscale // 2 (basicvsr.py:19)
     int trunk_base(int dir) const { return dir * (2 + 4 * rb); }
     int stem_w(int dir) const { return trunk_base(dir); }
     int stem_b(int dir) const { return trunk_base(dir) + 1; }
@@ -330,11 +336,11 @@ struct PIdx {
     int point_b() const { return point_w() + 1; }
     int up_w(int k) const { return point_w() + 2 + 2 * k; }
     int up_b(int k) const { return up_w(k) + 1; }
-    int last0_w() const { return point_w() + 6; }
-    int last0_b() const { return point_w() + 7; }
-    int last2_w() const { return point_w() + 8; }
-    int last2_b() const { return point_w() + 9; }
-    int spy_base() const { return point_w() + 10; }
+    int last0_w() const { return point_w() + 2 + 2 * ups; }
+    int last0_b() const { return last0_w() + 1; }
+    int last2_w() const { return last0_w() + 2; }
+    int last2_b() const { return last0_w() + 3; }
+    int spy_base() const { return last0_w() + 4; }
     int spy_w(int lvl, int j) const { return spy_base() + (lvl * NSPY + j) * 2; }
     int spy_b(int lvl, int j) const { return spy_w(lvl, j) + 1; }
     int spy_mean() const { return spy_base() + 60; }
@@ -414,7 +420,7 @@ int pack_all(const Ctx& c, const Plan& p, const float* const* prm) {
 }
 
 int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm) {
-    const PIdx ix{p.rb};
+    const PIdx ix{p.rb, p.ups};
     const int dt = c.dtype; (void)dt;
     for (int dir = 0; dir < 2; ++dir) {
         const float* sw = prm[ix.stem_w(dir)];
@@ -435,7 +441,7 @@ int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm) {
         if (p.bwd) CK(c.pack(prm[ix.point_w()], p.point_wd + (size_t)s * C * C * p.es, 1, C, C, C, C, 2 * C, s * C, 1, 0, 1));
     }
     CK(c.pack_bias(prm[ix.point_b()], p.point_b, C));
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < p.ups; ++k)
         for (int z = 0; z < 4; ++z) {
             // PixelShuffle(2): out[c, 2y+i, 2x+j] = conv[4c+2i+j, y, x]  => sub-conv z uses rows 4c+z
             CK(c.pack(prm[ix.up_w(k)], p.up_w[k] + (size_t)z * 9 * C * C * p.es, 9, C, C, C, C, C, 0, 4, z, 0));
@@ -457,6 +463,27 @@ int pack_all_collect(const Ctx& c, const Plan& p, const float* const* prm) {
 bool chain_on(const Plan& p) { return p.chain_mode != 0 && p.chain_sync[0] && p.chain_sync[1] && 2 * p.rb <= VSR_CHAIN_MAX_LAYERS; }
 unsigned chain_off(size_t o) { return (unsigned)(o >> 8); }
 int chain_launch(const Plan& p, const ChainArgs& a, hipStream_t st) {
+    // A batch of clips, image by image (r04).  Layer l + 1 reads what layer l has just written and what layer l - 1 wrote (the
+    // identity): with one 540p image in flight those ~200 MB live in the 256 MiB Infinity Cache, with two they do not -- measured on
+    // `bench.py --clips 2`: 37.0 us per image and layer in one launch of both against 34.6 us with one clip.  Large images only:
+    // small ones need both images' tiles to fill the chip.
+    const size_t img_bytes = (size_t)pm_image_elems(a.H, a.W, 64) * 2, sb_bytes = (size_t)cdiv(a.H, 8) * cdiv(a.W, 32) * 2048;
+    if (a.N > 1 && img_bytes * 3 * a.N > ((size_t)192 << 20) && cdiv(a.H, 8) * cdiv(a.W, 32) >= 2 * vsr_num_cus()) {
+        for (int m = 0; m < a.N; ++m) {
+            ChainArgs b = a;
+            b.N = 1;
+            const unsigned di = (unsigned)((m * img_bytes) >> 8), ds = (unsigned)((m * sb_bytes) >> 8);
+            for (int l = 0; l < a.nlayers; ++l) {
+                ChainLayer& L = b.layer[l];
+                L.src += di; L.dst += di;
+                if (L.res != 0xffffffffu) L.res += di;
+                if (L.sbits != 0xffffffffu) L.sbits += ds;
+                if (L.sout != 0xffffffffu) L.sout += ds;
+            }
+            CK(chain_launch(p, b, st));
+        }
+        return VSR_OK;
+    }
     if (p.chain_mode == 2) {            // diagnostic: the same kernel, one layer per launch (no hand-off between workgroups)
         for (int l = 0; l < a.nlayers; ++l) {
             ChainArgs b = a;
@@ -530,15 +557,16 @@ int recon_forward(const Ctx& c, const Plan& p, int i, const float* lrs, float* s
         CK(vsr_launch_conv(c.dtype, 1, 2, 64, 64, 0, 64, EPI_NHWC, a, c.st));
         if (p.bwd && c.dtype == VSR_BF16) CK(vsr_launch_sign_bits_c64(c.at(p.Pt[i]), c.at(p.SBPt[i]), n, h, w, c.st));   // mask of upsample.0's data gradient
     }
+    const int S = p.scale;                     // upscale: S / 2 PixelShufflePacks (basicvsr.py:19); U1 = U0 for S = 2 (Plan::build)
     CK(c.conv_ps(c.at(p.Pt[i]), p.up_w[0], c.fat(p.up_b[0]), c.at(p.U0[i]), n, h, w));
-    CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), n, 2 * h, 2 * w));
-    CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, n, 4 * h, 4 * w,
+    if (p.ups == 2) CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), n, 2 * h, 2 * w));
+    CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, n, S * h, S * w,
                 (p.bwd && c.dtype == VSR_BF16) ? c.at(p.SBC0[i]) : nullptr));
     {
-        ConvArgs a = c.base(n, 4 * h, 4 * w);   // conv_last.2 + bilinear x4 skip (basicvsr.py:21-22,82)
+        ConvArgs a = c.base(n, S * h, S * w);   // conv_last.2 + bilinear xS skip (basicvsr.py:21-22,82)
         a.src[0] = c.at(p.C0[i]); a.wpack = c.at(p.last2_w); a.bias = c.fat(p.last2_b); a.cout_real = 3;
-        a.dst[0] = sr + (size_t)i * 3 * 16 * h * w; a.dst_nstride = (long long)p.t * 3 * 16 * h * w;
-        a.base_lr = lrs + (size_t)i * 3 * h * w; a.base_nstride = (long long)p.t * 3 * h * w; a.base_h = h; a.base_w = w;
+        a.dst[0] = sr + (size_t)i * 3 * S * S * h * w; a.dst_nstride = (long long)p.t * 3 * S * S * h * w;
+        a.base_lr = lrs + (size_t)i * 3 * h * w; a.base_nstride = (long long)p.t * 3 * h * w; a.base_h = h; a.base_w = w; a.base_scale = S;
         CK(vsr_launch_conv(c.dtype, 3, 1, 64, 64, 0, 32, EPI_PLANAR, a, c.st));
     }
     return VSR_OK;
@@ -609,7 +637,7 @@ int forward_chain(const Ctx& c, const Plan& p, int dir, const float* lrs) {
 
 int forward_impl(const Plan& p, const float* const* prm, const float* lrs, float* sr, char* ws, hipStream_t st) {
     const Ctx c{p, ws, st, p.dtype, 0};
-    const PIdx ix{p.rb};
+    const PIdx ix{p.rb, p.ups};
     const int n = p.n, t = p.t;
     CK(pack_all(c, p, prm));
     if (t > 1) CK(spynet_run(c, p.spy, lrs, prm[ix.spy_mean()], prm[ix.spy_std()], n, t, 0, (float*)c.at(p.flows)));
@@ -734,14 +762,14 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
 }
 
 int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g, const float* last2_w) {
-    const PIdx ix{p.rb};
+    const PIdx ix{p.rb, p.ups};
     const WG wg{c};
     if (p.diet) {   // U0, U1 and C0 of this frame were not kept: the forward's three launches again (the sign bits of C0 were)
         CK(c.conv_ps(c.at(p.Pt[i]), p.up_w[0], c.fat(p.up_b[0]), c.at(p.U0[i]), p.n, p.h, p.w));
-        CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), p.n, 2 * p.h, 2 * p.w));
-        CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, p.n, 4 * p.h, 4 * p.w, nullptr));
+        if (p.ups == 2) CK(c.conv_ps(c.at(p.U0[i]), p.up_w[1], c.fat(p.up_b[1]), c.at(p.U1[i]), p.n, 2 * p.h, 2 * p.w));
+        CK(c.conv64(c.at(p.U1[i]), p.last0_w, c.fat(p.last0_b), c.at(p.C0[i]), ACT_LEAKY, nullptr, nullptr, 0, p.n, p.scale * p.h, p.scale * p.w, nullptr));
     }
-    const int n = p.n, h = p.h, w = p.w, H4 = 4 * h, W4 = 4 * w;
+    const int n = p.n, h = p.h, w = p.w, H4 = p.scale * h, W4 = p.scale * w;      // (the output size: 4h x 4w, or 2h x 2w for upscale 2)
     const float* dsr_i = dsr + (size_t)i * 3 * H4 * W4;
     const long long dsr_ns = (long long)p.t * 3 * H4 * W4;
     if (c.dtype == VSR_BF16 && last2_w) {   // d(conv_last.0 pre-activation) = dgrad(conv_last.2)(dsr) * LeakyReLU'(C0): hr_tail.hip
@@ -763,13 +791,15 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
         a.x[0] = c.at(p.U1[i]); a.dy[0] = c.at(p.G_C0);
         CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.last0_w()], C, 0, 1, 0, g[ix.last0_b()]));
     }
-    // upsample.1 (at 2h x 2w): dgrad, then wgrad per pixel-shuffle phase z
-    CK(c.conv_ps_dgrad(c.at(p.G_U1), p.up_wd[1], c.at(p.G_U0), nullptr, 0, n, 2 * h, 2 * w));
-    for (int z = 0; z < 4; ++z) {
-        WgradArgs a = wg_base(n, 2 * h, 2 * w);
-        a.x[0] = c.at(p.U0[i]); a.dy[0] = c.at(p.G_U1);
-        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = H4; a.Wy = W4; a.dy_nstride = pm_image_elems(H4, W4, C);
-        CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(1)], C, 0, 4, z, g[ix.up_b(1)]));
+    // upsample.1 (at 2h x 2w; upscale 4 only -- for upscale 2 G_U1 IS G_U0): dgrad, then wgrad per pixel-shuffle phase z
+    if (p.ups == 2) {
+        CK(c.conv_ps_dgrad(c.at(p.G_U1), p.up_wd[1], c.at(p.G_U0), nullptr, 0, n, 2 * h, 2 * w));
+        for (int z = 0; z < 4; ++z) {
+            WgradArgs a = wg_base(n, 2 * h, 2 * w);
+            a.x[0] = c.at(p.U0[i]); a.dy[0] = c.at(p.G_U1);
+            a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = H4; a.Wy = W4; a.dy_nstride = pm_image_elems(H4, W4, C);
+            CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(1)], C, 0, 4, z, g[ix.up_b(1)]));
+        }
     }
     // upsample.0 (at h x w): its input is LeakyReLU(point_conv) => mask with P
     CK(c.conv_ps_dgrad(c.at(p.G_U0), p.up_wd[0], c.at(p.G_P), c.at(p.Pt[i]), MASK_LEAKY, n, h, w, c.dtype == VSR_BF16 ? c.at(p.SBPt[i]) : nullptr));
@@ -831,7 +861,7 @@ int trunk_backward(const Ctx& c, const Plan& p, int dir, int i, const void* dtop
 
 // Weight gradients of one direction's trunk for the frames [f0, f1) (at most VSR_WG_MAXSEG per launch): the stem ...
 int stem_wgrads(const Ctx& c, const Plan& p, int dir, int f0, int f1, const float* lrs, float* const* g) {
-    const PIdx ix{p.rb};
+    const PIdx ix{p.rb, p.ups};
     const WG wg{c};
     const int n = p.n, t = p.t, h = p.h, w = p.w;
     {   // LR part (+ bias)
@@ -854,7 +884,7 @@ int stem_wgrads(const Ctx& c, const Plan& p, int dir, int f0, int f1, const floa
 }
 // ... and the two convs of ResidualConv block b
 int block_wgrads(const Ctx& c, const Plan& p, int dir, int b, int f0, int f1, float* const* g) {
-    const PIdx ix{p.rb};
+    const PIdx ix{p.rb, p.ups};
     const WG wg{c};
     WgradArgs a1 = wg_base(p.n, p.h, p.w), a2 = wg_base(p.n, p.h, p.w);
     a1.nseg = a2.nseg = 0;
@@ -906,8 +936,8 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
                   char* ws, hipStream_t st) {
     const Ctx c{p, ws, st, p.dtype, 0};
     // input gradient, part 1: the bilinear x4 skip (basicvsr.py:22,82) -- overwrites dlrs, everything else accumulates
-    if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st));
-    for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
+    if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st, p.scale));
+    for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb, p.ups}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
     Fork f{st, nullptr};
     // One stream: the two directions share their activation-gradient buffers (Plan::build), and chain launches of two streams could
     // each hold the CUs the other's unstarted workgroups need (conv3x3_chain.hip).  diet: rings per direction, no chains: two streams.
@@ -927,7 +957,7 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
             }
     }
     if (p.flowgrad && p.t > 1)   // part 3 (and train_flow): through the flows into SPyNet's parameters / image pyramid
-        CK(spynet_backward(c, p.spy, c.fat(p.dflows), p.n, p.t, 0, g, PIdx{p.rb}.spy_base(), dlrs, prm[PIdx{p.rb}.spy_std()]));
+        CK(spynet_backward(c, p.spy, c.fat(p.dflows), p.n, p.t, 0, g, PIdx{p.rb, p.ups}.spy_base(), dlrs, prm[PIdx{p.rb, p.ups}.spy_std()]));
     return VSR_OK;
 }
 
@@ -951,7 +981,7 @@ const char* vsr_status_string(int s) {
 
 int vsr_basicvsr_num_params(const VsrBasicVSRDesc* d) {
     if (!d || d->res_blocks < 0) return VSR_ERR_BADARG;
-    return PIdx{d->res_blocks}.count();
+    return PIdx{d->res_blocks, d->upscale == 2 ? 1 : 2}.count();
 }
 
 size_t vsr_basicvsr_workspace_bytes(const VsrBasicVSRDesc* d, int need_backward) {
@@ -966,7 +996,7 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
     if (!d || !params || !lrs || !sr || !workspace) return VSR_ERR_BADARG;
     Plan p;
     CK(p.build(*d, need_backward));
-    if (nparams != PIdx{p.rb}.count()) return VSR_ERR_BADARG;
+    if (nparams != PIdx{p.rb, p.ups}.count()) return VSR_ERR_BADARG;
     for (int k = 0; k < nparams; ++k) if (!params[k]) return VSR_ERR_BADARG;
     if (workspace_bytes < p.total) return VSR_ERR_WORKSPACE;
     return forward_impl(p, params, lrs, sr, (char*)workspace, (hipStream_t)stream);
@@ -976,7 +1006,7 @@ int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, 
                           const float* lrs, const float* dsr, float* dlrs, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !params || !grads || !lrs || !dsr || !workspace) return VSR_ERR_BADARG;
     if (d->res_blocks < 1) return VSR_ERR_UNSUPPORTED;
-    const PIdx ix{d->res_blocks};
+    const PIdx ix{d->res_blocks, d->upscale == 2 ? 1 : 2};
     if (nparams != ix.count()) return VSR_ERR_BADARG;
     bool flow = dlrs != nullptr;                           // input or SPyNet gradient wanted => the forward ran with need_backward = 2
     for (int k = ix.spy_base(); k < ix.spy_mean(); ++k) flow = flow || grads[k];

@@ -213,9 +213,9 @@ __global__ __launch_bounds__(LT_NT) void last2_dgrad_kernel(const float* __restr
     }
 }
 
-// PyTorch upsample_bilinear2d(align_corners=False) source index for scale 1/4 (basicvsr.py:22)
-__device__ __forceinline__ void hr_bil4(int d, int in_size, int& i0, int& i1, float& l1) {
-    float s = (d + 0.5f) * 0.25f - 0.5f;
+// PyTorch upsample_bilinear2d(align_corners=False) source index for scale `inv` = 1/4 (or 1/2: upscale = 2) (basicvsr.py:22)
+__device__ __forceinline__ void hr_bil4(int d, int in_size, int& i0, int& i1, float& l1, float inv = 0.25f) {
+    float s = (d + 0.5f) * inv - 0.5f;
     s = s < 0.f ? 0.f : s;
     i0 = (int)s;
     i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
@@ -318,7 +318,8 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
     const int yk = (oyr >> 2) - ((oyr & 3) < 2 ? 1 : 0), xk = (oxr >> 2) - ((oxr & 3) < 2 ? 1 : 0);
     const float wq[4] = {0.625f, 0.875f, 0.125f, 0.375f};
     const float lyc = wq[oyr & 3], lxc = wq[oxr & 3];
-    const bool fast = a.base_lr && !a.pres && a.cout_real == 3 && a.base_h * 4 == a.H && a.base_w * 4 == a.W;
+    const bool fast = a.base_lr && !a.pres && a.cout_real == 3 && a.base_scale != 2 && a.base_h * 4 == a.H && a.base_w * 4 == a.W;
+    const float binv = a.base_scale == 2 ? 0.5f : 0.25f;
     float bs[3] = {0.f, 0.f, 0.f};
     if (fast && a.bias) { bs[0] = a.bias[0]; bs[1] = a.bias[1]; bs[2] = a.bias[2]; }
     const long long lr_plane = (long long)a.base_h * a.base_w;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(FP_NT, 1) void c64_to_planar_kernel(const ConvArgs 
             ly = lyn; lx = lxn;
         } else if (ok) {
             int y0 = 0, y1 = 0, x0 = 0, x1 = 0; float ly = 0.f, lx = 0.f;
-            if (a.base_lr) { hr_bil4(oy, a.base_h, y0, y1, ly); hr_bil4(ox, a.base_w, x0, x1, lx); }
+            if (a.base_lr) { hr_bil4(oy, a.base_h, y0, y1, ly, binv); hr_bil4(ox, a.base_w, x0, x1, lx, binv); }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (c >= a.cout_real) break;

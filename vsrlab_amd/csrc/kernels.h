@@ -51,7 +51,7 @@ int vsr_launch_spynet_prepare_bwd(int dtype, const void* dx16, const float* dflo
                                   float* dflow_prev, float* dframes, int n, int t, int P, int pair_mode, int h, int w, hipStream_t st);
 int vsr_launch_avgpool2_bwd_add(const float* dcoarse, float* dfine, long long planes, int h, int w, hipStream_t st);
 int vsr_launch_resize_norm_bwd(const float* dnorm, float* dframes, const float* std, int F, int h, int w, int hu, int wu, hipStream_t st);
-int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int h, int w, hipStream_t st);
+int vsr_launch_bilinear4_bwd(const float* dsr, float* dlr, long long planes, int h, int w, hipStream_t st, int scale = 4);
 int vsr_launch_flow_out_bwd(const float* dout, float* din, int P, int hu, int wu, int h, int w, hipStream_t st);
 int vsr_launch_add_f32(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int vsr_launch_c64_to_planar(const ConvArgs& a, hipStream_t st);

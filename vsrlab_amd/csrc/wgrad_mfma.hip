@@ -407,7 +407,10 @@ __device__ uint4 g_zero_chunk[2];
 // LDS images mirror the blocked global layout so that a DMA piece reads long contiguous runs:
 //   X  : [10 rows][8 chunks][36 slots of 16 B]  (34 haloed pixels + 2 pad; chunk stride 576 B = 144 banks, so the
 //        4 chunks x 4 pixels x 8 B that a 32-lane half of ds_read_b64_tr_b16 touches fall on 64 distinct banks)
-//   dY : [ 8 rows][8 chunks][35 slots]          (32 pixels + 3 pad; 560 B: two 2-way pairs on the A reads only)
+//   dY : [ 8 rows][8 chunks][35 slots]          (32 pixels + 3 pad: 560 B = 140 banks, 12 mod 64 -- the two chunks c, c + 1 that a half
+//        of an A read touches overlapped in one pixel's four banks: 27.6 % of this kernel's LDS cycles were bank conflicts, r03
+//        PMC.  r04: the pixels of the ODD chunks sit one slot later (slot = pixel + (c & 1), still inside the chunk's 35 slots), which
+//        makes the distance 144 banks = 16 mod 64 like the X image's: conflict-free.  Measured: DESIGN 4.2.)
 // 2 x (46,080 + 35,840) B = exactly the 160 KiB of a CU.
 constexpr int XS = 36, YS = 35;                      // slots per chunk row
 constexpr int XROW = 8 * XS * 16, YROW = 8 * YS * 16;   // 4,608 / 4,480 bytes per tile row
@@ -442,6 +445,7 @@ static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
 // ---------------------------------------------------------------------------------------------------
 // Diagnostic build only (make ABL=<bits> ABLSRC=wgrad_mfma): bit 0: the producers issue only the first tile's DMA (consumer-only
 // period); bit 1: the consumers skip the K loop (producer-only period).  Results are wrong by construction; only run time is read.
+// bit 2: the round-3 dY image (no slot shift of the odd chunks: bank conflicts on the A reads; results unchanged) for the A/B.
 // (r03: "B fragments for the ky = 0 groups only" measured -4 % with the DMA on, -7 % without: the K loop now shares an X row's
 // fragments across ky.)
 #ifdef VSR_ABL
@@ -450,6 +454,7 @@ __device__ unsigned long long g_wclk[256 * 4];          // [workgroup][cycles, 1
 #else
 #define WABL(bit) 0
 #endif
+#define DY_SHIFT (WABL(2) ? 0 : 1)      // slots by which the pixels of an odd chunk are shifted in the dY image
 __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -503,10 +508,10 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
             } else {
                 const int idx = (piece - DX_PIECES) * 64 + lane;
                 const int row = idx / (8 * YS), rem = idx - row * (8 * YS);
-                const int c = rem / YS, tx = rem - c * YS;
-                const int dx = tx * a.dy_step + a.dy_ox;
+                const int c = rem / YS, tx = rem - c * YS - (c & 1) * DY_SHIFT;       // tx: the pixel of this slot
+                const int dx = (tx < 0 ? 0 : tx) * a.dy_step + a.dy_ox;
                 rel[i] = ((((row * a.dy_step) * pm_ws(a.Wy) + (dx >> 5)) * ycp + c) * 256 + (dx & 31) * 8) * 2;
-                if (tx >= TW) padmask |= 1u << i;
+                if (tx < 0 || tx >= TW) padmask |= 1u << i;
             }
         }
         // (segment, image, tile row, tile column) of the walk, advanced by adds and carries (four runtime divisions per tile
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                         valid = vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
                     } else {
                         const int idx = (piece - DX_PIECES) * 64 + lane;
-                        const int row = idx / (8 * YS), tx = (idx - row * (8 * YS)) % YS;
+                        const int row = idx / (8 * YS), rem = idx - row * (8 * YS), c = rem / YS, tx = rem - c * YS - (c & 1) * DY_SHIFT;
                         valid = ty0 + row < a.H && tx0 + tx < a.W;
                     }
                 }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
             // the chip's LDS-DMA rate), and anything in front of the issue delays the whole transfer.  The bias-gradient partial
             // sums of the CURRENT dY tile follow, read by inline asm (hipcc would put a vmcnt(0) in front of a plain LDS read
             // while LDS-DMA is in flight; the DMA writes the OTHER buffer set).
-            const unsigned lyb = (unsigned)(cur * DSET + DXB + (pt & 7) * (YS * 16) + (pt >> 3) * 16);
+            const unsigned lyb = (unsigned)(cur * DSET + DXB + (pt & 7) * (YS * 16) + ((pt >> 3) + (pt & 1) * DY_SHIFT) * 16);
             advance();
             if (it.T < walk.end && !WABL(0)) issue(cur ^ 1);
             uint4 bq[8];
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
         // 8 q + qq, channels 4 p4 .. 4 p4 + 3 of the fragment's 16; lane i of the group receives channel i of pixels
         // 8 q .. 8 q + 3 (second read, + 64 B: 8 q + 4 .. 8 q + 7) = the 16x16x32 operand's k = 8 q .. 8 q + 7.
         const int xoff = (ib * 4 + (p4 >> 1)) * (XS * 16) + (8 * q + qq) * 16 + (p4 & 1) * 8;
-        const int yoff = DXB + (cb * 4 + (p4 >> 1)) * (YS * 16) + (8 * q + qq) * 16 + (p4 & 1) * 8;
+        const int yoff = DXB + (cb * 4 + (p4 >> 1)) * (YS * 16) + (8 * q + qq + (p4 >> 1) * DY_SHIFT) * 16 + (p4 & 1) * 8;   // chunk parity = p4 >> 1
         typedef union { s16x4_t s[2]; bf16x8_t b; } frag_u;
         f32x4_t acc[9][2][2];
 #pragma unroll

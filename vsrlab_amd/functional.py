@@ -774,6 +774,47 @@ class _DiscriminatorFn(torch.autograd.Function):
         return (dimg, None, None, None) + tuple(g if need_p[k] else None for k, g in enumerate(grads)) + (None,) * 16
 
 
+class _SpectralNormFn(torch.autograd.Function):
+    """weight = weight_orig / sigma(weight_orig; u, v): torch.nn.utils.spectral_norm's ``compute_weight`` (one power iteration per
+    training-mode forward, u and v updated IN PLACE, sigma = u . (W v) differentiated through W only) as ``vsr_spectral_norm`` /
+    ``vsr_spectral_norm_backward`` -- what the discriminator function above does for its eight inner layers, for ONE layer."""
+
+    @staticmethod
+    def forward(ctx, worig, u, v, training):
+        lib = _lib.load()
+        w32 = _f32c(worig)
+        co = w32.shape[0]
+        k = w32.numel() // co
+        weff = torch.empty_like(w32)
+        sigma = torch.empty(1, dtype=torch.float32, device=w32.device)
+        _lib.check(lib.vsr_spectral_norm(_ptr(w32), _ptr(u), _ptr(v), _ptr(weff), _ptr(sigma), co, k, int(training), _stream()), "spectral_norm")
+        ctx.save_for_backward(w32, u.detach().clone(), v.detach().clone(), sigma)          # the constants of THIS forward's graph
+        return weff
+
+    @staticmethod
+    def backward(ctx, geff):
+        w32, u, v, sigma = ctx.saved_tensors
+        lib = _lib.load()
+        co = w32.shape[0]
+        gorig = torch.zeros_like(w32)
+        scratch = torch.empty(1024, dtype=torch.float32, device=w32.device)                 # VSR_SN_SCRATCH_FLOATS
+        _lib.check(lib.vsr_spectral_norm_backward(_ptr(_f32c(geff)), _ptr(w32), _ptr(u), _ptr(v), _ptr(sigma), _ptr(gorig), co, w32.numel() // co,
+                                                  _ptr(scratch), _stream()), "spectral_norm_backward")
+        return gorig, None, None, None
+
+
+def spectral_conv_forward(x: torch.Tensor, weight_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, training: bool,
+                          compute_dtype: Optional[str] = None) -> torch.Tensor:
+    """SpectralConv.forward (core/modules/conv.py:6-13) on its own, for the shape the per-layer kernels serve: 3x3, stride 1,
+    padding 1, 64 -> 64 (the discriminator's conv_7 / conv_8 shape; the wide and the 4x4 stride-2 layers exist only inside the
+    discriminator engine).  Differentiable w.r.t. x and weight_orig; u / v are updated in place when ``training``."""
+    _require_gpu(x, weight_orig)
+    if tuple(weight_orig.shape) != (64, 64, 3, 3) or x.shape[1] != 64:
+        raise NotImplementedError("standalone HIP SpectralConv: Conv2d(64, 64, 3, 1, 1); other shapes run inside UNetDiscriminator")
+    weff = _SpectralNormFn.apply(weight_orig, u, v, bool(training))
+    return _conv_layer_autograd(x, None, weff, None, 0, compute_dtype=compute_dtype)
+
+
 def discriminator_forward(img: torch.Tensor, params: Sequence[torch.Tensor], buffers: Sequence[torch.Tensor], training: bool,
                           compute_dtype: Optional[str] = None) -> torch.Tensor:
     """``params``: conv_0.weight, conv_0.bias, conv_1..8 ``weight_orig``, conv_9.weight, conv_9.bias; ``buffers``:
