@@ -516,8 +516,12 @@ def test_basicvsr_upscale_2_vs_golden_and_oracle(dtype):
 
     if dtype == "fp32":
         assert rel_err(sr, g["sr"]) < 1e-3
-        _, _, g32 = oracle("fp32")
-        _fp32_noise_floor_check(grads, g32, {k: v.double() for k, v in ref.items()})
+        # as for the upscale-4 golden above: fixed bounds on this shallow net.  What is left of the error is ONE LeakyReLU mask flip (an
+        # element of conv_last.0's output within fp32 rounding of zero: conv_last.0 and everything upstream at ~1e-3, conv_last.2 at
+        # 1e-6; two other seeds: one clean at 1e-6 everywhere, one with a flip at point_conv's output) -- the noise-floor ratio against
+        # the fp32 oracle's own flips (2.8e-4 here) is a coin toss at this depth
+        glob, worst, cos = _grad_report(grads, ref)
+        assert glob < 1e-3 and worst[0] < 5e-3 and cos > 0.999999, (glob, worst, cos)
         assert rel_l2(dl, g["grad_lrs"]) < 2e-2, rel_l2(dl, g["grad_lrs"])        # (the SPyNet share carries fp32 ReLU-mask noise)
     else:
         sr_e, dl_e, g_e = oracle("emu")

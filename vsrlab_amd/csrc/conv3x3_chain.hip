@@ -64,7 +64,8 @@ constexpr int NPIECE_W = (NPIECE_T + 3) / 4;                              // 11;
 // order (every A read = 1 KiB contiguous) instead of [cout row][8 swizzled chunks] -- same results, an energy experiment; bit 16: no A
 // (weight) fragment reads for the taps of kernel row ky = 1 (the upper bound of what holding that row's 24 fragments = 96 registers
 // per lane in registers would save: round-3 VERDICT next #1a); bit 17: only the first 8 of the 18 K steps = 128 of 288 MFMAs and
-// 64 of 144 fragment reads per tile and wave (the matrix work of a Winograd F(2x2, 3x3) kernel WITHOUT its transforms: VERDICT #1c).  On the
+// 64 of 144 fragment reads per tile and wave (the matrix work of a Winograd F(2x2, 3x3) kernel WITHOUT its transforms: VERDICT #1c);
+// bit 18: a new layer's weights are loaded at the layer change itself (round 3's exposed L2 round trip) instead of a tile ahead.  On the
 // back-to-back leg the kernel's time is its energy, so these price the energy of LDS reads / DMA / stores.
 #ifdef VSR_ABL
 #define CABL(bit) ((VSR_ABL >> (bit)) & 1)
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
 
 #define W_LOAD(wv, wg)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
-        const int idx = tid + i * 256;                                                                                   \
+        const int idx = (tid & 255) + i * 256;        /* 256 threads stage a weight set: the MFMA waves or the producers */ \
         const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
         wv[i] = (wg)[(tap * 64 + pm_acc_chan(r >> 4, r & 15)) * 8 + c];                                                  \
     }
 #define W_STORE(wv)                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                                    \
-        const int idx = tid + i * 256;                                                                                   \
+        const int idx = (tid & 255) + i * 256;                                                                           \
         const int tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;                                                      \
         *reinterpret_cast<u32x4_t*>(lds_w + (CABL(15) ? ((((tap * 2 + (c >> 2)) * 4 + (r >> 4)) * 64 + (c & 3) * 16 + (r & 15)) * 16) : tap * 8192 + (r * 8 + (c ^ ((r >> 1) & 7))) * 16)) = wv[i]; \
     }
@@ -252,6 +253,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             const int dx = tx - 1;
             rel[i] = ((((ty - 1) * WS + (dx >> 5)) * 8 + c) * 256 + (dx & 31) * 8) * 2;
         }
+        u32x4_t wvp[WCH];                                          // the next layer's weights on their way to LDS
+        float bvp = 0.f;
+        const int pt = tid - 256;
         int p_layer = -1;
         const char* p_src = nullptr;
         auto issue = [&](int layer, int n, int tyi, int txi, int buf) {
@@ -295,9 +299,37 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             // The MFMA waves' weight reload of a layer change: joined FIRST.  Behind the dependency wait below it would deadlock:
             // the MFMA waves would sit in this barrier in front of tile k while the wait is for tile k-1's deferred publish,
             // which they make in tile k's epilogue.
-            if (layer_k != cur_layer) { cur_layer = layer_k; __syncthreads(); }
+            if (layer_k != cur_layer) {
+                // r04: the PRODUCERS stage a new layer's weights.  They were requested a whole tile ago (below) and are in registers;
+                // the weight image is free (every MFMA wave is past the K loop of the previous tile: the barrier that ended it).
+                // Before, the MFMA waves loaded, waited and wrote here, with the L2 round trip exposed once per layer and workgroup.
+                cur_layer = layer_k;
+                if (CABL(18)) {                                        // (diagnostic: the loads exposed here, as in round 3)
+                    const auto* wgx = GP(const u32x4_t, base + (unsigned long long)ka.layer[layer_k].w * 256ull);
+                    W_LOAD(wvp, wgx)
+                    const unsigned bo = ka.layer[layer_k].bias;
+                    bvp = 0.f;
+                    if (pt < 64 && bo != 0xffffffffu) bvp = GP(const float, base + (unsigned long long)bo * 256ull)[pm_acc_chan(pt >> 4, pt & 15)];
+                }
+                W_STORE(wvp)
+                if (pt < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[pt] = bvp;
+                __syncthreads();
+            }
             int* s1 = ctl + 8 * ((k + 1) % 3);
             const int it1 = __builtin_amdgcn_readfirstlane(s1[0]);
+            // the next item opens a new layer: its 72 KiB of packed weights (18 x 16 bytes per producer thread) and its bias are
+            // requested now, the OLDEST vector-memory operations of this iteration (the leader's counted wait below looks at the
+            // youngest ones only); they are written to LDS at the top of the next iteration
+            if (it1 >= 0 && !CABL(18)) {
+                const int l1w = __builtin_amdgcn_readfirstlane(s1[1]);
+                if (l1w != cur_layer) {
+                    const auto* wgx = GP(const u32x4_t, base + (unsigned long long)ka.layer[l1w].w * 256ull);
+                    W_LOAD(wvp, wgx)
+                    const unsigned bo = ka.layer[l1w].bias;
+                    bvp = 0.f;
+                    if (pt < 64 && bo != 0xffffffffu) bvp = GP(const float, base + (unsigned long long)bo * 256ull)[pm_acc_chan(pt >> 4, pt & 15)];
+                }
+            }
             // the leader asks for item k+2 first: the atomic's round trip runs under the poll / DMA issue below
             unsigned nx = 0xffffffffu;                                    // (never a counter value)
             const bool fetch = leader && it1 >= 0;
@@ -337,7 +369,7 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
         }
     } else {
         // =================== MFMA waves ===================
-        u32x4_t wv[WCH];
+        u32x4_t wv[WCH];                                           // the FIRST layer's weights (prologue only: the producers are busy with the first tile)
         {
             const auto* wg = GP(const u32x4_t, base + (unsigned long long)ka.layer[ctl[1]].w * 256ull);
             W_LOAD(wv, wg)
@@ -395,16 +427,9 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_chain_kernel(const ChainAr
             const int* sn = ctl + 8 * ((k + 1) % 3);     // the next item: read behind the K loop (registers), used at the end of the tile
             int nx_item = -1, nx_layer = 0, nx_n = 0, nx_ty = 0, nx_tx = 0, nx_ok = 0;
             if (layer != cur_layer) {
-                // every MFMA wave is past the previous tile's K loop (the barrier at its end): the weight image is free
+                // (the producers write the new weight image and bias: see there)
                 cur_layer = layer;
                 layer_ptrs(layer);
-                const auto* wg = GP(const u32x4_t, base + (unsigned long long)ka.layer[layer].w * 256ull);
-                W_LOAD(wv, wg)
-                float bv = 0.f;
-                const unsigned bo = ka.layer[layer].bias;
-                if (tid < 64 && bo != 0xffffffffu) bv = GP(const float, base + (unsigned long long)bo * 256ull)[pm_acc_chan(tid >> 4, tid & 15)];
-                W_STORE(wv)
-                if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = bv;
                 __syncthreads();
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) bvec[mb] = *reinterpret_cast<const f32x4_t*>(smem + BIAS_OFF + (mb * 16 + 4 * q) * 4);
