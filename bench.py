@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic clip per GPU: HIP forward of
-BasicVSR(64, 30, 4) on (1,7,3,540,960), fused Charbonnier loss + its gradient, HIP backward (all
+One "step" = one pass of the hot path over one batch of synthetic clips per GPU (default: two 7-frame 540x960
+clips; --clips 1 = the rounds 1-3 workload): HIP forward of
+BasicVSR(64, 30, 4) on (2,7,3,540,960), fused Charbonnier loss + its gradient, HIP backward (all
 weight gradients, written straight into the optimizer's flat gradient arena), ONE RCCL all-reduce of
 that arena when N > 1, and the reference's update_weights tail (core/utils.py:270-280:
 clip_grad_norm_(1) + Adam + zero_grad) as the fused HIP step -- kept inside the timed region so that
@@ -315,7 +316,11 @@ def main():
                     help="N > 1: flat = one all-reduce over the gradient arena (vsrlab_amd.parallel.FlatGradSync); ddp = torch DistributedDataParallel")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel leg (for rocprofv3 PMC passes)")
     ap.add_argument("--train-flow", action="store_true", help="train_flow=True (conf/experiment/basic.yaml:7): SPyNet is differentiated too (need_backward = 2)")
-    ap.add_argument("--clips", type=int, default=1, help="clips per GPU and step (BASELINE configs[3] 'batch-of-clips'; 2 fit a GPU with --arena diet)")
+    ap.add_argument("--clips", type=int, default=2,
+                    help="7-frame clips per GPU and step (BASELINE configs[1] '7-frame clips' / configs[3] 'batch-of-clips'; the reference's per-rank "
+                         "micro-batch is 8 clips, conf/experiment/basic.yaml:10,25-26).  Two fit one 288 GB GPU in the full arena since round 4 "
+                         "(105 GiB per clip) and run 2.3 % faster per frame than one (same kernels on twice the tiles per launch, the trunk chains "
+                         "image by image); --clips 1 is the round 1-3 workload")
     ap.add_argument("--arena", default="full", choices=["full", "diet"],
                     help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 131 GiB per clip, all-frames weight-gradient launches "
                          "(the headline configuration); diet = 65 GiB per clip (per-frame weight gradients, HR activations recomputed)")

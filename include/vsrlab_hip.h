@@ -16,7 +16,7 @@
  *
  * Tensor conventions
  *   boundary tensors are the reference's own: LR clip (n,t,3,h,w) fp32 planar, SR clip
- *   (n,t,3,4h,4w) fp32 planar, parameters/gradients fp32 OIHW, flow (N,2,H,W) fp32 planar with
+ *   (n,t,3,S h,S w) fp32 planar (S = upscale), parameters/gradients fp32 OIHW, flow (N,2,H,W) fp32 planar with
  *   channel 0 = dx.  "pm" (pixel-major) tensors are the library's internal BLOCKED layout
  *       [N][H][ceil(W/32)][C/8][32 pixels][8 channels]          (csrc/common.h: pm_off())
  *   with element type `dtype` (VSR_DT_F32 / VSR_DT_BF16) and C a multiple of 16: inside a 32-pixel row segment
@@ -47,8 +47,12 @@ const char* vsr_status_string(int status);
 
 /* ---- whole-path engine -------------------------------------------------------------------
  * Replaces BasicVSR.forward and its autograd backward (basicvsr.py:39-83).
- * mid_channels must be 64 and upscale 4 (the reference's defaults, basicvsr.py:12-13);
- * res_blocks >= 1; t <= 32 (test.py's window).                                              */
+ * mid_channels must be 64 (the reference's default, basicvsr.py:12-13); upscale 4 (default: two
+ * PixelShufflePacks, x4 bilinear skip) or 2 (ONE PixelShufflePack = upscale // 2, conv_last at 2h x 2w,
+ * x2 bilinear skip: basicvsr.py:19-22; conf/train/model/basicvsr.yaml:4 takes the scale from the dataset
+ * config); res_blocks >= 1; t <= 32 (test.py's window).  A trunk-chain launch that gave up a dependency
+ * wait (csrc/conv3x3_chain.hip) overwrites the head of its last image with NaN: sr / the gradients of
+ * that call are then not finite -- results of such a call are never silently wrong.            */
 typedef struct VsrBasicVSRDesc {
     int n, t, h, w;      /* LR clip (n,t,3,h,w) */
     int mid_channels;
@@ -56,10 +60,12 @@ typedef struct VsrBasicVSRDesc {
     int upscale;
     int dtype;           /* VSR_DT_* of the internal activations */
     int arena_mode;      /* training workspace (ABI 3): 0 = every activation and activation gradient of the clip stays in the
-                          * workspace and the weight gradients run as all-frames launches (fastest; 127 GiB at BASELINE config 2);
+                          * workspace and the weight gradients run as all-frames launches (fastest; 105 GiB per clip at BASELINE config 2
+                          * since round 4 -- the two propagation directions share one set of activation-gradient buffers, the backward
+                          * runs them one after the other -- so two clips fit one 288 GB GPU);
                           * 1 = "diet": the trunks' activation gradients live in a two-block ring and each frame's weight gradients
                           * are launched behind its data gradients; the two HR tensors of a frame (upsample.1 / conv_last.0 outputs)
-                          * are recomputed in the backward (63 GiB at config 2, two clips per 288 GB GPU; same results up to the
+                          * are recomputed in the backward (65 GiB at config 2; +18 % time per step; same results up to the
                           * summation order of the weight gradients over frames).  Ignored by inference (need_backward = 0).     */
 } VsrBasicVSRDesc;
 
@@ -67,7 +73,7 @@ typedef struct VsrBasicVSRDesc {
  * itself lists spynet.mean/std before the SPyNet convs; this ABI puts them last):
  *   for trunk in (backward_resblocks, forward_resblocks):
  *       conv.0.weight, conv.0.bias, then res_block.{i}.conv1.{weight,bias}, conv2.{weight,bias}
- *   point_conv.0.{weight,bias}; upsample.{0,1}.upconv.{weight,bias};
+ *   point_conv.0.{weight,bias}; upsample.{0,1}.upconv.{weight,bias} (upscale 2: upsample.0 only);
  *   conv_last.0.{weight,bias}; conv_last.2.{weight,bias};
  *   spynet.basic_module.{0..5}.basic_module.{0..4}.conv.0.{weight,bias}; spynet.mean; spynet.std */
 int vsr_basicvsr_num_params(const VsrBasicVSRDesc* d);
@@ -83,13 +89,13 @@ int vsr_basicvsr_forward(const VsrBasicVSRDesc* d, const float* const* params, i
                          const float* lrs, float* sr, void* workspace, size_t workspace_bytes,
                          int need_backward, void* stream);
 
-/* Back-propagates dsr (n,t,3,4h,4w) through the forward that last ran on `workspace`
+/* Back-propagates dsr (n,t,3,S h,S w) through the forward that last ran on `workspace`
  * (need_backward >= 1).  grads[k] (same order/shape as params; NULL = not wanted) are ACCUMULATED
  * into (+=).  SPyNet entries: all NULL = frozen flow net; otherwise the forward must have run with
  * need_backward = 2 and all 60 conv tensors get their gradient (flow gradient of the propagation
  * warps, spynet.py:95-106, then SPyNet's own backward, spynet.py:38-93).
  * dlrs (n,t,3,h,w) fp32 or NULL: the gradient w.r.t. the input clip is WRITTEN here (what RealBasicVSR's
- * pre-clean stack receives): bilinear x4 skip + the stems' LR channels + the flows through SPyNet's image
+ * pre-clean stack receives): bilinear xS skip + the stems' LR channels + the flows through SPyNet's image
  * pyramid; also needs need_backward = 2.                                                        */
 int vsr_basicvsr_backward(const VsrBasicVSRDesc* d, const float* const* params, float* const* grads,
                           int nparams, const float* lrs, const float* dsr, float* dlrs, void* workspace,

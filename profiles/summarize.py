@@ -123,6 +123,39 @@ def main():
                       "per_variant": per, "algorithmic_GBs": round(tot_b / tot_t / 1e3, 1), "frac_of_8TBs": round(tot_b / tot_t / 1e3 / 8000.0, 4)}
     json.dump(out, open(os.path.join(here, f"{tag}_roofline.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    lds_conflicts(src, tag, here, out.get("csrc_sha1"), out.get("git_head"))
+
+
+def lds_conflicts(src, tag, here, sha1, head):
+    """<tag>_lds_conflicts.md from pmc_lds/ (rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py
+    --train-flow --clips 1 --steps 1 --warmup 1 --no-cpu-baseline): conflict cycles / active cycles per kernel, summed over its launches.
+    Stamped with the profiled tree's csrc_sha1 (round-3 VERDICT #11: a stale file under a "final tree" heading)."""
+    path = os.path.join(src, "pmc_lds", "lds_counter_collection.csv")
+    if not os.path.exists(path):
+        return
+    tree = {"csrc_sha1": sha1, "git_head": head}
+    try:
+        for line in open(os.path.join(src, "pmc_lds.log")):
+            if line.startswith("{") and '"tree"' in line:
+                tree = json.loads(line)["tree"]
+    except OSError:
+        pass
+    acc = defaultdict(lambda: defaultdict(float))
+    launches = defaultdict(set)
+    for r in rows(path):
+        k = r["Kernel_Name"]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k].add(r["Dispatch_Id"])
+    lines = [f"# LDS bank conflicts per kernel over `bench.py --train-flow --clips 1 --steps 1 --warmup 1` under rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE",
+             f"# profiled tree: csrc_sha1 {tree.get('csrc_sha1')}, git {tree.get('git_head')} (written by profiles/summarize.py {tag}; regenerate with profiles/{tag}_commands.sh)",
+             "", "| kernel | launches | SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE |", "|---|---|---|"]
+    for k in sorted(acc):
+        a = acc[k]
+        if a.get("SQ_LDS_IDX_ACTIVE", 0) <= 0 or "rocclr" in k or "at::" in k:
+            continue
+        lines.append(f"| `{k[:70]}` | {len(launches[k])} | {a.get('SQ_LDS_BANK_CONFLICT', 0.0) / a['SQ_LDS_IDX_ACTIVE']:.4f} |")
+    open(os.path.join(here, f"{tag}_lds_conflicts.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 if __name__ == "__main__":
