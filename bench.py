@@ -322,7 +322,7 @@ def main():
                          "(105 GiB per clip) and run 2.3 % faster per frame than one (same kernels on twice the tiles per launch, the trunk chains "
                          "image by image); --clips 1 is the round 1-3 workload")
     ap.add_argument("--arena", default="full", choices=["full", "diet"],
-                    help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 131 GiB per clip, all-frames weight-gradient launches "
+                    help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 105 GiB per clip, all-frames weight-gradient launches "
                          "(the headline configuration); diet = 65 GiB per clip (per-frame weight gradients, HR activations recomputed)")
     args = ap.parse_args()
     if args.optimizer == "torch" and args.dp == "flat":
