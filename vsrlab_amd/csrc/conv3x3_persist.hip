@@ -126,9 +126,21 @@ __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) { unsigne
 __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// Diagnostic bit 8: nt on the tile DMA; bit 9: nt on the output stores.  tools/bw_probe.hip streams reads at 6.4-7.0 TB/s with nt against
+// 5.7-6.2 without, and out of cache (tools/ab_conv.py, 8 rotating buffer sets) nt STORES take 7 % off a bias+ReLU launch (36.7 -> 34.0 us;
+// bias+skip 42.3 -> 41.5; nt loads: 36.2 / 44.3) -- but inside a step, applied to the outputs of >= 512 MB (the 16P tensors of the
+// reconstruction), the step is 0.2-0.7 ms SLOWER (124.6-124.9 -> 125.1-125.6 ms, three interleaved pairs): their consumers do find the
+// tail of such a tensor in the Infinity Cache.  Not used (r04).
+#ifdef VSR_ABL
+#define P_DMA_AUX (((VSR_ABL >> 8) & 1) ? 2 : 0)
+#define P_NT_STORE ((VSR_ABL >> 9) & 1)
+#else
+#define P_DMA_AUX 0
+#define P_NT_STORE 0
+#endif
 #define GLDS16(src, dst)                                                                              \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, P_DMA_AUX)
 
 // Epilogue variants are compile-time: a runtime-selected epilogue serialises 16 load->use->store
 // chains per tile (measured: 14 us of a 71 us launch).
@@ -508,7 +520,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
                             for (int jj = 0; jj < 4; ++jj) ow[jj] = pk_bf16(v[2 * jj], v[2 * jj + 1]);
                         }
                         const u32x4_t o = {ow[0], ow[1], ow[2], ow[3]};
-                        if (!ABL(5)) *GP(u32x4_t, dst + k * 1024) = o;
+                        if (P_NT_STORE) __builtin_nontemporal_store(o, GP(u32x4_t, dst + k * 1024));
+                        else if (!ABL(5)) *GP(u32x4_t, dst + k * 1024) = o;
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }

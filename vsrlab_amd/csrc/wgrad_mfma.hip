@@ -445,7 +445,8 @@ static_assert(DX_SLOTS % 64 == 0 && DY_SLOTS % 64 == 0, "whole DMA pieces");
 // ---------------------------------------------------------------------------------------------------
 // Diagnostic build only (make ABL=<bits> ABLSRC=wgrad_mfma): bit 0: the producers issue only the first tile's DMA (consumer-only
 // period); bit 1: the consumers skip the K loop (producer-only period).  Results are wrong by construction; only run time is read.
-// bit 2: the round-3 dY image (no slot shift of the odd chunks: bank conflicts on the A reads; results unchanged) for the A/B.
+// bit 2: the round-3 dY image (no slot shift of the odd chunks: bank conflicts on the A reads; results unchanged) for the A/B;
+// bit 3: nt instead of the default cache policy on the producers. LDS-DMA pieces (results unchanged).
 // (r03: "B fragments for the ky = 0 groups only" measured -4 % with the DMA on, -7 % without: the K loop now shares an X row's
 // fragments across ky.)
 #ifdef VSR_ABL
@@ -455,6 +456,11 @@ __device__ unsigned long long g_wclk[256 * 4];          // [workgroup][cycles, 1
 #define WABL(bit) 0
 #endif
 #define DY_SHIFT (WABL(2) ? 0 : 1)      // slots by which the pixels of an odd chunk are shifted in the dY image
+// X and dY are streamed: every byte is read once per launch (halo rows twice, by a neighbour tile of the same XCD in flight at the same
+// time).  `nt` (aux = 2) on the LDS-DMA pieces: tools/bw_probe.hip reads 8 GiB at 6.4-7.0 TB/s with nt loads against 5.7-6.2 with plain
+// ones -- but this kernel does not care: 233.2 / 231.7 us (nt) against 230.1 / 234.3 (default) per 7-frame launch, the same 349 k cycles:
+// its producers are bound by the issue cost of their 80 pieces per tile, not by the policy.  Default policy kept; diagnostic bit 3 = nt.
+#define WG_DMA_AUX (WABL(3) ? 2 : 0)
 __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(DNT, 2) void wgrad3x3_c64_pc_kernel(const WgradArgs
                 if (!valid) src = zsrc;
                 char* dst = isx ? lxs + piece * 1024 : lxs + DXB + (piece - DX_PIECES) * 1024;
                 if (!pad) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                                           (__attribute__((address_space(3))) void*)dst, 16, 0, WG_DMA_AUX);
             }
         };
         float bsum[8];
