@@ -129,8 +129,8 @@ def test_workspace_query_and_unsupported_configs_fail_loudly():
     for mode in (1, 2):
         full_b, diet_b = lib.vsr_basicvsr_workspace_bytes(ctypes.byref(d), mode), lib.vsr_basicvsr_workspace_bytes(ctypes.byref(diet), mode)
         assert 0 < diet_b <= 70 * 2 ** 30 and diet_b < 0.65 * full_b, (mode, diet_b / 2 ** 30, full_b / 2 ** 30)
-        # the full arena (r04: ONE set of trunk activation gradients for both directions, 131 -> 105 GiB): two clips fit 288 GB as well
-        assert full_b <= 112 * 2 ** 30, (mode, full_b / 2 ** 30)
+        # the full arena (r04: ONE set of trunk activation gradients for both directions, per-frame gradients into the reconstruction's shuffle layers: 131 -> 113 GiB): two clips fit 288 GB as well
+        assert full_b <= 120 * 2 ** 30, (mode, full_b / 2 ** 30)
     assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(diet), 0) == infer
     assert lib.vsr_basicvsr_workspace_bytes(ctypes.byref(_lib.BasicVSRDesc(1, 7, 540, 960, 64, 30, 4, 1, 2)), 1) == 0
     # upscale 2 (one PixelShufflePack: basicvsr.py:19) is supported since round 4: two tensors fewer, a smaller arena

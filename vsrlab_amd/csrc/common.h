@@ -79,6 +79,12 @@ struct ConvArgs {
     // uses 0.2 (unet-discriminator.py:19)
     float leaky_slope;
     int planar_c;                        // channels of a planar fp32 source (LASTPLANAR): 0 = 3
+    // conv3x3_c64_persist only (r04): the destination (and the residual, which has the destination's layout) is stored PHASE-SEPARATED:
+    // pixel (y, x) of the Hd x Wd image goes to plane z = 2 (y & 1) + (x & 1), position (y >> 1, x >> 1) of four Hd/2 x Wd/2 images
+    // (each a whole N-image tensor, `unshuffle_plane` elements apart; dst_nstride = one Hd/2 x Wd/2 image).  What a pixel-shuffle
+    // layer's gradients read is then four contiguous tensors instead of every second pixel of every second row.  Hd, Wd even.
+    int unshuffle;
+    long long unshuffle_plane;
 };
 static inline __host__ __device__ float vsr_slope(float s) { return s != 0.f ? s : 0.1f; }
 

@@ -154,15 +154,15 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
     // launch to the first piece; the first tile is the critical path of the prologue).
     const int z = blockIdx.y;
     struct {
-        int N, H, W, Ws, Wd, in_step, out_step, src_ox0, src_oy0, out_oxz, out_oyz, bias_zstride;
-        long long src_nstride0, dst_nstride, w_zstride;
+        int N, H, W, Ws, Wd, in_step, out_step, src_ox0, src_oy0, out_oxz, out_oyz, bias_zstride, unshuffle;
+        long long src_nstride0, dst_nstride, w_zstride, plane;
         unsigned long long src0, wpack, resz, auxz, sign_bitsz, dstz, sign_outz, bias; float leaky_slope;   // pointers as integers: GP() below
-    } a = {ka.N, ka.H, ka.W, ka.Ws, ka.Wd, ka.in_step, ka.out_step, ka.src_ox[0], ka.src_oy[0], ka.out_ox[z], ka.out_oy[z], ka.bias_zstride,
-           ka.src_nstride[0], ka.dst_nstride, ka.w_zstride,
+    } a = {ka.N, ka.H, ka.W, ka.Ws, ka.Wd, ka.in_step, ka.out_step, ka.src_ox[0], ka.src_oy[0], ka.out_ox[z], ka.out_oy[z], ka.bias_zstride, ka.unshuffle,
+           ka.src_nstride[0], ka.dst_nstride, ka.w_zstride, ka.unshuffle_plane,
            (unsigned long long)ka.src[0], (unsigned long long)ka.wpack, (unsigned long long)ka.res[z], (unsigned long long)ka.aux[z],
            (unsigned long long)ka.sign_bits[z], (unsigned long long)ka.dst[z], (unsigned long long)ka.sign_out[z], (unsigned long long)ka.bias, ka.leaky_slope};
     asm volatile("" : "+s"(a.N), "+s"(a.H), "+s"(a.W), "+s"(a.Ws), "+s"(a.Wd), "+s"(a.in_step), "+s"(a.out_step), "+s"(a.src_ox0), "+s"(a.src_oy0),
-                 "+s"(a.out_oxz), "+s"(a.out_oyz), "+s"(a.bias_zstride), "+s"(a.src_nstride0), "+s"(a.dst_nstride), "+s"(a.w_zstride));
+                 "+s"(a.out_oxz), "+s"(a.out_oyz), "+s"(a.bias_zstride), "+s"(a.unshuffle), "+s"(a.src_nstride0), "+s"(a.dst_nstride), "+s"(a.w_zstride), "+s"(a.plane));
     asm volatile("" : "+s"(a.src0), "+s"(a.wpack), "+s"(a.resz), "+s"(a.auxz), "+s"(a.sign_bitsz), "+s"(a.dstz), "+s"(a.sign_outz), "+s"(a.bias), "+s"(a.leaky_slope));
     // a pinned pointer comes back as an integer: name its address space, or hipcc addresses it with flat_ instructions
 #define GP(T, x) ((__attribute__((address_space(1))) T*)(x))
@@ -312,6 +312,10 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
         for (int nb = 0; nb < 4; ++nb) {
             const int dx = ((nb & 1) * 16 + pxl) * a.out_step + a.out_oxz;
             loff[nb] = ((((w4 * 2 + (nb >> 1)) * a.out_step) * WSd + (dx >> 5)) * 8 + q) * 256 + (dx & 31) * 8;
+            if (a.unshuffle) {      // phase-separated destination (ConvArgs::unshuffle): plane 2 (row & 1) + (px & 1), position (row >> 1, px >> 1)
+                const int row = w4 * 2 + (nb >> 1), px = (nb & 1) * 16 + pxl;
+                loff[nb] = (int)(((row & 1) * 2 + (px & 1)) * a.plane) + (((row >> 1) * pm_ws(a.Wd >> 1)) * 8 + q) * 256 + (px >> 1) * 8;
+            }
         }
         W_STORE(wv)
         STAMP(m1);
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(PNT, 1) void conv3x3_c64_persist_kernel(const ConvA
             STAMP(t0);
             // epilogue operands, requested now, used after the K loop
             const int tile = it.tile, n = it.n, ty0 = it.ty * PTH, tx0 = it.tx * PTW;
-            const long long tbase = (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oyz, tx0 * a.out_step, 0, a.Wd, 64);
+            const long long tbase = a.unshuffle ? (long long)n * a.dst_nstride + pm_off(ty0 >> 1, tx0 >> 1, 0, a.Wd >> 1, 64)      // (tx0 >> 1: a multiple of 16)
+                                                : (long long)n * a.dst_nstride + pm_off(ty0 * a.out_step + a.out_oyz, tx0 * a.out_step, 0, a.Wd, 64);
             // a tile inside the image (all but the last tile row / column of a ragged size) needs no per-lane bounds: straight-line
             // operand loads and epilogue (wave-uniform choice)
             const bool full = ty0 + PTH <= a.H && tx0 + PTW <= a.W;
@@ -631,6 +636,12 @@ int vsr_launch_conv3x3_c64_persist(const ConvArgs& a, int num_cus, hipStream_t s
     }
     if (pm_image_elems((PTHH + 2) * a.in_step, a.Ws, 64) * 2 > 0x7fffffffLL || pm_image_elems(2 * PTH + 2, a.Wd, 64) > 0x7fffffffLL)
         return VSR_ERR_UNSUPPORTED;                                                  // in-tile offsets are 32-bit
+    if (a.unshuffle) {                                         // phase-separated destination: plain stride-1 launches without an activation-mask operand
+        if (a.nz != 1 || a.out_step != 1 || a.out_ox[0] || a.out_oy[0] || (a.Hd & 1) || (a.Wd & 1) || a.Hd != a.H || a.Wd != a.W || aux ||
+            a.unshuffle_plane < (long long)a.N * pm_image_elems(a.Hd / 2, a.Wd / 2, 64) || a.dst_nstride != pm_image_elems(a.Hd / 2, a.Wd / 2, 64) ||
+            3 * a.unshuffle_plane + pm_image_elems(PTH + 2, a.Wd / 2, 64) > 0x7fffffffLL)
+            return VSR_ERR_UNSUPPORTED;
+    }
 #define PERSIST_CASE(ACT, RES, MASK) if (a.act == ACT && res == RES && mask == MASK) return launch_persist<ACT, RES, MASK>(a, num_cus, st);
     PERSIST_CASE(ACT_RELU, false, MASK_NONE)     // conv1 of a ResidualConv
     PERSIST_CASE(ACT_NONE, true, MASK_NONE)      // conv2 + skip ; dgrad(conv1) + dX

@@ -502,6 +502,7 @@ int vsr_launch_conv(int dtype, int ks, int nsrc, int ca, int cb, int last_planar
         const int ps = vsr_launch_conv3x3_c64_persist(a, vsr_num_cus(), st);
         if (ps != VSR_ERR_UNSUPPORTED) return ps;
     }
+    if (a.unshuffle) return VSR_ERR_UNSUPPORTED;               // the phase-separated destination exists in the persistent kernel only
     // 64 -> (<= 4) channels with a planar destination: streaming kernel of hr_tail.hip
     if (dtype == VSR_BF16 && ks == 3 && nsrc == 1 && ca == 64 && cb == 64 && !last_planar && cout_t == 32 && epi == EPI_PLANAR &&
         !vsr_force_generic_conv()) {

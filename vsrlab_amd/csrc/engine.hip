@@ -89,6 +89,7 @@ struct Plan {
     bool diet;                   // VsrBasicVSRDesc.arena_mode = 1 (training only): see vsrlab_hip.h
     int rb, n, t, h, w, dtype;
     int scale, ups;              // upscale (2 or 4, basicvsr.py:12-23) and its PixelShufflePack count scale / 2
+    bool unsh;                   // the gradients INTO the pixel-shuffle layers (G_U1, G_U0) are kept phase-separated (ConvArgs::unshuffle)
     size_t es;
     size_t px1;                 // elements of one blocked (n,h,w,64) tensor
     size_t s_elems;             // elements of the plain 64-bit fixed-point warp-scatter accumulator (n,h,w,64)
@@ -118,6 +119,11 @@ struct Plan {
     size_t chain_sync[2] = {0, 0};              // counters of the trunk chain launches (0: chains not planned)
     int chain_mode = 1;                         // VSRLAB_AMD_CHAIN, read ONCE per engine call (build()): 0 one launch per layer, 1 chains, 2 diagnostic
     size_t G_C0, G_U1, G_U0, G_P;
+    // r04 (full arena, bf16): the gradients into the two pixel-shuffle layers and into the 1x1 fuse conv are kept PER FRAME (+9.8 GB per
+    // clip at config 2), so that those layers' weight gradients are all-frames launches like the trunks' (28 + 28 + 14 one-frame launches
+    // of 50-140 us each per step before: a one-frame launch at LR size is mostly prologue, slab write and first-tile latency)
+    bool hrdef = false;
+    std::vector<size_t> GU1f, GU0f, GPf;
     size_t dflows;              // fp32 planar, layout of `flows`: gradient w.r.t. the flows (train_flow / input gradient)
     size_t stem_wd_lr[2];       // data-gradient weights of the stems' 3 LR input channels (input gradient)
     size_t total;
@@ -136,7 +142,7 @@ struct Plan {
         if (d.arena_mode != 0 && d.arena_mode != 1) return VSR_ERR_BADARG;
         diet = bwd && d.arena_mode == 1;
         rb = d.res_blocks; n = d.n; t = d.t; h = d.h; w = d.w; dtype = d.dtype;
-        scale = d.upscale; ups = scale / 2;
+        scale = d.upscale; ups = scale / 2; unsh = false;
         if (d.mid_channels != C || (scale != 4 && scale != 2) || rb < 1 || n < 1 || t < 1 || t > 32 || h < 1 || w < 1) return VSR_ERR_UNSUPPORTED;
         if (dtype != VSR_F32 && dtype != VSR_BF16) return VSR_ERR_BADARG;
         es = esize(dtype);
@@ -221,8 +227,20 @@ struct Plan {
             G_C0 = b.take(a4); G_P = b.take(a1);
             // diet: dU1 is written after C0's last use and dU0 after U1's (recon_backward): they take those buffers
             // (upscale 2: there is no U1 / dU1; dU0 is conv_last.0's data gradient and takes C0's buffer in the diet arena)
-            if (ups == 2) { if (diet) { G_U1 = C0[0]; G_U0 = U1[0]; } else { G_U1 = b.take(a4); G_U0 = b.take(a2); } }
-            else { G_U0 = diet ? C0[0] : b.take(a2); G_U1 = G_U0; }
+            // r04 (full arena, bf16, persistent kernels): both are stored as four phase planes, whose 32-pixel row padding can exceed the
+            // whole image's (2 ceil(x) >= ceil(2 x)): four planes of the next lower resolution each
+            unsh = !diet && dtype == VSR_BF16 && !vsr_env().generic_conv;
+            const size_t gu1 = unsh && 4 * a2 > a4 ? 4 * a2 : a4, gu0 = unsh && 4 * a1 > a2 ? 4 * a1 : a2;
+            if (ups == 2) { if (diet) { G_U1 = C0[0]; G_U0 = U1[0]; } else { G_U1 = b.take(gu1); G_U0 = b.take(gu0); } }
+            else { G_U0 = diet ? C0[0] : b.take(gu0); G_U1 = G_U0; }
+            hrdef = unsh;
+            GU1f.assign(t, G_U1); GU0f.assign(t, G_U0); GPf.assign(t, G_P);
+            if (hrdef)
+                for (int i = 1; i < t; ++i) {             // frame 0 keeps the buffers above
+                    GU0f[i] = b.take(gu0);
+                    GU1f[i] = ups == 2 ? b.take(gu1) : GU0f[i];
+                    GPf[i] = b.take(a1);
+                }
             int cp, xp, stride;
             vsr_wgrad_slab_dims(3, 64, 64, &cp, &xp, &stride);
             for (int k = 0; k < 2; ++k) slab[k] = b.take((size_t)VSR_WGRAD_NWG * stride * 4);
@@ -262,12 +280,18 @@ struct Ctx {
         for (int s = 0; s < VSR_MAX_SRC; ++s) a.src_nstride[s] = pm_image_elems(H, W, C);
         return a;
     }
+    // the destination of `a` (an N x H x W x 64 image, H and W even) as four phase planes of N x H/2 x W/2 x 64 (ConvArgs::unshuffle)
+    static long long plane_elems(int N, int H, int W) { return (long long)N * pm_image_elems(H / 2, W / 2, C); }
+    static void set_unshuffle(ConvArgs& a, int N, int H, int W) {
+        a.unshuffle = 1; a.unshuffle_plane = plane_elems(N, H, W); a.dst_nstride = pm_image_elems(H / 2, W / 2, C);
+    }
     // y = act(conv3x3(x) + bias) (+res) (*mask(aux)) -- 64 -> 64 at one resolution
     int conv64(const void* x, size_t wpack, const float* bias, void* y, int act, const void* res, const void* aux, int mask,
-               int N, int H, int W, void* sign_out = nullptr, const void* sign_bits = nullptr) const {
+               int N, int H, int W, void* sign_out = nullptr, const void* sign_bits = nullptr, bool unshuffle = false) const {
         ConvArgs a = base(N, H, W);
         a.src[0] = x; a.wpack = at(wpack); a.bias = bias; a.dst[0] = y; a.act = act; a.res[0] = res; a.aux[0] = aux; a.mask_mode = mask;
         a.sign_out[0] = sign_out; a.sign_bits[0] = sign_bits;
+        if (unshuffle) set_unshuffle(a, N, H, W);
         return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
     }
     // conv3x3 64->256 + PixelShuffle(2): x (N,H,W,64) -> y (N,2H,2W,64)   (upsampling.py:10-12)
@@ -283,14 +307,23 @@ struct Ctx {
     // four weight sets do not fit LDS together), phase z reading phase z-1's partial sum as its residual in place --
     // the partial sums pass through bf16 three times (~1.6x the rounding error of the final store alone), for
     // 560 us instead of 1470 us at 1080x1920.  fp32: one generic 4-source launch, accumulated in registers.
-    int conv_ps_dgrad(const void* dy, size_t wpackd, void* dx, const void* aux, int mask, int N, int H, int W, const void* sign_bits = nullptr) const {
+    // dy_planes: dy is stored phase-separated (four N x H x W planes, written by a launch with ConvArgs::unshuffle): phase z is then a
+    // contiguous tensor instead of every second pixel of every second row of the 2H x 2W image (r04: the strided form fetched every
+    // line of dy twice per data gradient and again twice per weight gradient); dx_planes: write dx phase-separated in turn.
+    int conv_ps_dgrad(const void* dy, size_t wpackd, void* dx, const void* aux, int mask, int N, int H, int W, const void* sign_bits = nullptr,
+                      bool dy_planes = false, bool dx_planes = false) const {
         if (dtype == VSR_BF16) {
             for (int z = 0; z < 4; ++z) {
                 ConvArgs a = base(N, H, W);
-                a.in_step = 2; a.Hs = 2 * H; a.Ws = 2 * W;
-                a.src[0] = dy; a.src_oy[0] = z >> 1; a.src_ox[0] = z & 1; a.src_nstride[0] = pm_image_elems(2 * H, 2 * W, C);
+                if (dy_planes) {
+                    a.src[0] = (const char*)dy + (size_t)z * plane_elems(N, 2 * H, 2 * W) * p.es;      // plane z: N x H x W, stride 1 (base() set it up)
+                } else {
+                    a.in_step = 2; a.Hs = 2 * H; a.Ws = 2 * W;
+                    a.src[0] = dy; a.src_oy[0] = z >> 1; a.src_ox[0] = z & 1; a.src_nstride[0] = pm_image_elems(2 * H, 2 * W, C);
+                }
                 a.wpack = at(wpackd + (size_t)z * 9 * C * C * p.es); a.dst[0] = dx;
                 a.res[0] = z > 0 ? dx : nullptr;
+                if (dx_planes) set_unshuffle(a, N, H, W);
                 if (z == 3) { a.aux[0] = aux; a.mask_mode = mask; a.sign_bits[0] = aux ? sign_bits : nullptr; }
                 int rc = vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
                 if (rc != VSR_OK) return rc;
@@ -761,6 +794,45 @@ int spynet_backward(const Ctx& c, const SpyPlan& sp, const float* dflows_out, in
     return VSR_OK;
 }
 
+// Weight gradients of PixelShufflePack k (upsample.k, upsampling.py:7) for the frames [f0, f1): one launch per pixel-shuffle phase z,
+// X = the layer's input, dY = phase z of the gradient into it (a contiguous plane when p.unsh, else every second pixel of every second row)
+int recon_ps_wgrads(const Ctx& c, const Plan& p, int k, int f0, int f1, float* const* g) {
+    const PIdx ix{p.rb, p.ups};
+    const WG wg{c};
+    const int n = p.n, H = (k + 1) * p.h, W = (k + 1) * p.w;              // the layer's input size: h x w (k = 0), 2h x 2w (k = 1)
+    for (int i0 = f0; i0 < f1; i0 += VSR_WG_MAXSEG) {
+        const int i1 = i0 + VSR_WG_MAXSEG < f1 ? i0 + VSR_WG_MAXSEG : f1;
+        for (int z = 0; z < 4; ++z) {
+            WgradArgs a = wg_base(n, H, W);
+            a.nseg = 0;
+            for (int i = i0; i < i1; ++i) {
+                a.x[a.nseg] = c.at(k == 1 ? p.U0[i] : p.Pt[i]);
+                const char* gu = (const char*)c.at(k == 1 ? p.GU1f[i] : p.GU0f[i]);
+                a.dy[a.nseg] = p.unsh ? gu + (size_t)z * Ctx::plane_elems(n, 2 * H, 2 * W) * p.es : gu;      // plane z: n x H x W, contiguous
+                ++a.nseg;
+            }
+            if (!p.unsh) { a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = 2 * H; a.Wy = 2 * W; a.dy_nstride = pm_image_elems(2 * H, 2 * W, C); }
+            CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(k)], C, 0, 4, z, g[ix.up_b(k)]));
+        }
+    }
+    return VSR_OK;
+}
+// ... and of the 1x1 fuse conv on cat([outputs[i], feat_prop]) (basicvsr.py:18,75-77): one launch per 64-channel half of its input
+int recon_point_wgrads(const Ctx& c, const Plan& p, int f0, int f1, float* const* g) {
+    const PIdx ix{p.rb, p.ups};
+    const WG wg{c};
+    for (int i0 = f0; i0 < f1; i0 += VSR_WG_MAXSEG) {
+        const int i1 = i0 + VSR_WG_MAXSEG < f1 ? i0 + VSR_WG_MAXSEG : f1;
+        for (int s = 0; s < 2; ++s) {
+            WgradArgs a = wg_base(p.n, p.h, p.w);
+            a.nseg = 0;
+            for (int i = i0; i < i1; ++i) { a.x[a.nseg] = c.at(p.feat[s][i]); a.dy[a.nseg] = c.at(p.GPf[i]); ++a.nseg; }
+            CK(wg.run(1, 64, false, 64, false, a, C, C, g[ix.point_w()], 2 * C, s * C, 1, 0, s == 0 ? g[ix.point_b()] : nullptr));
+        }
+    }
+    return VSR_OK;
+}
+
 int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const float* dsr, float* const* g, const float* last2_w) {
     const PIdx ix{p.rb, p.ups};
     const WG wg{c};
@@ -785,7 +857,9 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
         a.x[0] = c.at(p.C0[i]); a.dy[0] = dsr_i; a.dy_nstride = dsr_ns;
         CK(wg.run(3, 64, false, 16, true, a, 3, C, g[ix.last2_w()], C, 0, 1, 0, g[ix.last2_b()]));
     }
-    CK(c.conv64(c.at(p.G_C0), p.last0_wd, nullptr, c.at(p.G_U1), ACT_NONE, nullptr, nullptr, 0, n, H4, W4));
+    // (r04: G_U1 / G_U0, the gradients into the pixel-shuffle layers, are written phase-separated when p.unsh)
+    const size_t gu1 = p.GU1f[i], gu0 = p.GU0f[i], gp = p.GPf[i];     // (per frame when p.hrdef: their weight gradients run later, all frames per launch)
+    CK(c.conv64(c.at(p.G_C0), p.last0_wd, nullptr, c.at(gu1), ACT_NONE, nullptr, nullptr, 0, n, H4, W4, nullptr, nullptr, p.unsh));
     {   // conv_last.0: X = U1, dY = G_C0
         WgradArgs a = wg_base(n, H4, W4);
         a.x[0] = c.at(p.U1[i]); a.dy[0] = c.at(p.G_C0);
@@ -793,33 +867,19 @@ int recon_backward(const Ctx& c, const Plan& p, int i, const float* lrs, const f
     }
     // upsample.1 (at 2h x 2w; upscale 4 only -- for upscale 2 G_U1 IS G_U0): dgrad, then wgrad per pixel-shuffle phase z
     if (p.ups == 2) {
-        CK(c.conv_ps_dgrad(c.at(p.G_U1), p.up_wd[1], c.at(p.G_U0), nullptr, 0, n, 2 * h, 2 * w));
-        for (int z = 0; z < 4; ++z) {
-            WgradArgs a = wg_base(n, 2 * h, 2 * w);
-            a.x[0] = c.at(p.U0[i]); a.dy[0] = c.at(p.G_U1);
-            a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = H4; a.Wy = W4; a.dy_nstride = pm_image_elems(H4, W4, C);
-            CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(1)], C, 0, 4, z, g[ix.up_b(1)]));
-        }
+        CK(c.conv_ps_dgrad(c.at(gu1), p.up_wd[1], c.at(gu0), nullptr, 0, n, 2 * h, 2 * w, nullptr, p.unsh, p.unsh));
+        if (!p.hrdef) CK(recon_ps_wgrads(c, p, 1, i, i + 1, g));
     }
     // upsample.0 (at h x w): its input is LeakyReLU(point_conv) => mask with P
-    CK(c.conv_ps_dgrad(c.at(p.G_U0), p.up_wd[0], c.at(p.G_P), c.at(p.Pt[i]), MASK_LEAKY, n, h, w, c.dtype == VSR_BF16 ? c.at(p.SBPt[i]) : nullptr));
-    for (int z = 0; z < 4; ++z) {
-        WgradArgs a = wg_base(n, h, w);
-        a.x[0] = c.at(p.Pt[i]); a.dy[0] = c.at(p.G_U0);
-        a.dy_step = 2; a.dy_oy = z >> 1; a.dy_ox = z & 1; a.Hy = 2 * h; a.Wy = 2 * w; a.dy_nstride = pm_image_elems(2 * h, 2 * w, C);
-        CK(wg.run(3, 64, false, 64, false, a, C, C, g[ix.up_w(0)], C, 0, 4, z, g[ix.up_b(0)]));
-    }
+    CK(c.conv_ps_dgrad(c.at(gu0), p.up_wd[0], c.at(gp), c.at(p.Pt[i]), MASK_LEAKY, n, h, w, c.dtype == VSR_BF16 ? c.at(p.SBPt[i]) : nullptr, p.unsh, false));
+    if (!p.hrdef) CK(recon_ps_wgrads(c, p, 0, i, i + 1, g));
     {   // point_conv dgrad: two 64-channel outputs (d outputs[i], d feat_prop)
         ConvArgs a = c.base(n, h, w);
-        a.src[0] = c.at(p.G_P); a.wpack = c.at(p.point_wd); a.w_zstride = C * C; a.nz = 2;
+        a.src[0] = c.at(gp); a.wpack = c.at(p.point_wd); a.w_zstride = C * C; a.nz = 2;
         a.dst[0] = c.at(p.dFeatB[i]); a.dst[1] = c.at(p.dFF[i]);
         CK(vsr_launch_conv(c.dtype, 1, 1, 64, 64, 0, 64, EPI_NHWC, a, c.st));
     }
-    for (int s = 0; s < 2; ++s) {
-        WgradArgs a = wg_base(n, h, w);
-        a.x[0] = c.at(p.feat[s][i]); a.dy[0] = c.at(p.G_P);
-        CK(wg.run(1, 64, false, 64, false, a, C, C, g[ix.point_w()], 2 * C, s * C, 1, 0, s == 0 ? g[ix.point_b()] : nullptr));
-    }
+    if (!p.hrdef) CK(recon_point_wgrads(c, p, i, i + 1, g));
     return VSR_OK;
 }
 
@@ -938,6 +998,11 @@ int backward_impl(const Plan& p, const float* const* prm, float* const* g, const
     // input gradient, part 1: the bilinear x4 skip (basicvsr.py:22,82) -- overwrites dlrs, everything else accumulates
     if (dlrs) CK(vsr_launch_bilinear4_bwd(dsr, dlrs, (long long)p.n * p.t * 3, p.h, p.w, st, p.scale));
     for (int i = p.t - 1; i >= 0; --i) CK(recon_backward(c, p, i, lrs, dsr, g, prm ? prm[PIdx{p.rb, p.ups}.last2_w()] : nullptr));   // -> dFeatB[i], dFF[i]
+    if (p.hrdef) {            // the weight gradients recon_backward left out: all frames per launch
+        if (p.ups == 2) CK(recon_ps_wgrads(c, p, 1, 0, p.t, g));
+        CK(recon_ps_wgrads(c, p, 0, 0, p.t, g));
+        CK(recon_point_wgrads(c, p, 0, p.t, g));
+    }
     Fork f{st, nullptr};
     // One stream: the two directions share their activation-gradient buffers (Plan::build), and chain launches of two streams could
     // each hold the CUs the other's unstarted workgroups need (conv3x3_chain.hip).  diet: rings per direction, no chains: two streams.
