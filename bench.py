@@ -319,10 +319,10 @@ def main():
     ap.add_argument("--clips", type=int, default=2,
                     help="7-frame clips per GPU and step (BASELINE configs[1] '7-frame clips' / configs[3] 'batch-of-clips'; the reference's per-rank "
                          "micro-batch is 8 clips, conf/experiment/basic.yaml:10,25-26).  Two fit one 288 GB GPU in the full arena since round 4 "
-                         "(105 GiB per clip) and run 2.3 % faster per frame than one (same kernels on twice the tiles per launch, the trunk chains "
+                         "(113 GiB per clip) and run ~2 % faster per frame than one (same kernels on twice the tiles per launch, the trunk chains "
                          "image by image); --clips 1 is the round 1-3 workload")
     ap.add_argument("--arena", default="full", choices=["full", "diet"],
-                    help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 105 GiB per clip, all-frames weight-gradient launches "
+                    help="training workspace of the engine (VsrBasicVSRDesc.arena_mode): full = 113 GiB per clip, all-frames weight-gradient launches "
                          "(the headline configuration); diet = 65 GiB per clip (per-frame weight gradients, HR activations recomputed)")
     args = ap.parse_args()
     if args.optimizer == "torch" and args.dp == "flat":

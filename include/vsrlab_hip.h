@@ -60,7 +60,7 @@ typedef struct VsrBasicVSRDesc {
     int upscale;
     int dtype;           /* VSR_DT_* of the internal activations */
     int arena_mode;      /* training workspace (ABI 3): 0 = every activation and activation gradient of the clip stays in the
-                          * workspace and the weight gradients run as all-frames launches (fastest; 105 GiB per clip at BASELINE config 2
+                          * workspace and the weight gradients run as all-frames launches (fastest; 113 GiB per clip at BASELINE config 2
                           * since round 4 -- the two propagation directions share one set of activation-gradient buffers, the backward
                           * runs them one after the other -- so two clips fit one 288 GB GPU);
                           * 1 = "diet": the trunks' activation gradients live in a two-block ring and each frame's weight gradients

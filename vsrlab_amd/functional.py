@@ -555,7 +555,7 @@ _ARENA_MODE: Optional[int] = None
 
 def set_arena_mode(mode: Optional[str]) -> None:
     """Training workspace of the BasicVSR engine (VsrBasicVSRDesc.arena_mode, include/vsrlab_hip.h): "full" (default: every
-    activation gradient of a direction kept, all-frames weight-gradient launches; 105 GiB per clip for BASELINE config 2) or "diet" (65 GiB: per-frame
+    activation gradient of a direction kept, all-frames weight-gradient launches; 113 GiB per clip for BASELINE config 2) or "diet" (65 GiB: per-frame
     weight gradients behind a two-block gradient ring, HR activations recomputed; for batch-of-clips per GPU).  None: back to
     $VSRLAB_AMD_ARENA (unset = "full")."""
     global _ARENA_MODE
