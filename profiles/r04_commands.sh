@@ -12,6 +12,8 @@ VSRLAB_AMD_SINGLE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o rl -- python3 bench.py --roofline-only > $O/pmc_fetch.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o rl -- python3 bench.py --roofline-only > $O/pmc_write.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o rl -- python3 bench.py --roofline-only > $O/pmc_mfma.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_step_fetch -o st -- python3 bench.py --clips 1 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_step_fetch.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_step_write -o st -- python3 bench.py --clips 1 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_step_write.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_lds -o lds -- python3 bench.py --train-flow --clips 1 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_lds.log 2>&1 &&
 timeout -k 10 200 python tools/ab_chain.py vsrlab_amd/lib/libvsrlab_hip.so vsrlab_amd/lib/libvsrlab_hip_conv3x3_chain_abl0.so > $O/clock_chain.log 2>&1 &&
 timeout -k 10 200 python tools/ab_conv.py 5 libvsrlab_hip.so libvsrlab_hip_conv3x3_persist_abl0.so > $O/clock.log 2>&1 &&

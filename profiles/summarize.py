@@ -121,6 +121,34 @@ def main():
            "backward chain <CHAIN_MASK>, 59 layers": {"launches": len(bw), "avg_us": round(tb / max(len(bw), 1), 1), "avg_us_per_layer": round(tb / max(len(bw), 1) / 59, 2)}}
     out["in_step"] = {"what": "the trunk chains of conv3x3_c64_chain_kernel inside one timed step (single-stream trace), call-weighted",
                       "per_variant": per, "algorithmic_GBs": round(tot_b / tot_t / 1e3, 1), "frac_of_8TBs": round(tot_b / tot_t / 1e3 / 8000.0, 4)}
+    # ---- HBM bytes of the dominant kernels INSIDE a step (r04): FETCH_SIZE / WRITE_SIZE passes over `bench.py --clips 1 --steps 1 --warmup 1`
+    # (pmc_step_fetch/, pmc_step_write/), per launch, against the algorithmic bytes of the same launch.  In the step a layer's input was
+    # written one layer earlier: what the counters show below the algorithmic read bytes is served by the 256 MiB Infinity Cache. ----
+    try:
+        def per_kernel(d, counter):
+            vals, names = defaultdict(float), {}
+            for r in rows(os.path.join(src, d, "st_counter_collection.csv")):
+                if r["Counter_Name"] == counter:
+                    k = int(r["Dispatch_Id"]); vals[k] += float(r["Counter_Value"]); names[k] = r["Kernel_Name"]
+            return vals, names
+        fv, fn = per_kernel("pmc_step_fetch", "FETCH_SIZE")
+        wv, wn = per_kernel("pmc_step_write", "WRITE_SIZE")
+        def mean_of(vals, names, pred, drop_last=0):
+            ks = [k for k in sorted(vals) if pred(names[k])]
+            ks = ks[:len(ks) - drop_last] if drop_last else ks
+            return (sum(vals[k] for k in ks) / len(ks), len(ks)) if ks else (0.0, 0)
+        st = {}
+        for tag2, pred, drop, alg in (("forward chain, 60 layers", lambda n: KERN in n and "<0>" in n, CHAIN_ITERS + 2, alg_fw),
+                                      ("backward chain, 59 layers", lambda n: KERN in n and "<2>" in n, 0, alg_bw),
+                                      ("wgrad3x3_c64_pc (all launches of the step)", lambda n: "wgrad3x3_c64_pc" in n, 0, None)):
+            f, nf = mean_of(fv, fn, pred, drop)
+            w, nw = mean_of(wv, wn, pred, drop)
+            st[tag2] = {"launches": nf, "fetch_x2_GB_per_launch": round(2.0 * f * 1024 / 1e9, 3), "write_GB_per_launch": round(w * 1024 / 1e9, 3)}
+            if alg:
+                st[tag2]["algorithmic_GB_per_launch"] = round(alg / 1e9, 3)
+        out["in_step_traffic"] = st
+    except (OSError, KeyError, ZeroDivisionError):
+        pass
     json.dump(out, open(os.path.join(here, f"{tag}_roofline.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
     lds_conflicts(src, tag, here, out.get("csrc_sha1"), out.get("git_head"))

@@ -1271,6 +1271,26 @@ def test_a_real_chain_timeout_is_loud_in_a_subprocess():
     assert "RAISED 1" in r.stdout, r.stdout
 
 
+def test_generic_kernel_switches_in_subprocesses():
+    """VSRLAB_AMD_GENERIC_CONV=1 (an A/B switch read once per process: every 3x3 64 -> 64 convolution outside the trunk chains on the generic
+    tiled kernel instead of the persistent one; the gradients into the pixel-shuffle layers stay in the strided layout).  Round 4 found it
+    broken since round 2 -- the generic kernel writes no sign bits, conv_last.2's data gradient read garbage ones (gradient error 0.53) --
+    and fixed it in Ctx::conv64; the whole-path goldens run again in a child with the switch on, also with one launch per layer."""
+    _gpu()
+    import subprocess
+    import sys
+    # (not the upscale-2 test: its diet-vs-full comparison to 1e-5 presumes the same kernels in both arenas, and with the switch on the diet
+    # arena's per-layer backward runs on the generic kernel while the full arena's chains do not)
+    sel = "test_basicvsr_end_to_end_vs_golden or test_basicvsr_train_flow_vs_golden or test_ragged_sizes_and_single_frame"
+    # ... and the other process-wide implementation switches of INTEGRATION.md section 5 while a child is being paid for anyway
+    for extra in ({"VSRLAB_AMD_GENERIC_CONV": "1"}, {"VSRLAB_AMD_GENERIC_CONV": "1", "VSRLAB_AMD_CHAIN": "0"}, {"VSRLAB_AMD_GENERIC_WGRAD": "1"},
+                  {"VSRLAB_AMD_SINGLE_STREAM": "1", "VSRLAB_AMD_CHAIN": "0"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (extra, r.stdout[-2000:] + r.stderr[-2000:])
+
+
 def test_parity_suite_on_the_diet_arena_in_a_subprocess():
     """The whole-path parity tests again with VSRLAB_AMD_ARENA=diet (goldens, oracle, noise-floor criteria unchanged): the switch
     is process-wide, so they run in a child."""

@@ -292,7 +292,11 @@ struct Ctx {
         a.src[0] = x; a.wpack = at(wpack); a.bias = bias; a.dst[0] = y; a.act = act; a.res[0] = res; a.aux[0] = aux; a.mask_mode = mask;
         a.sign_out[0] = sign_out; a.sign_bits[0] = sign_bits;
         if (unshuffle) set_unshuffle(a, N, H, W);
-        return vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+        const int rc = vsr_launch_conv(dtype, 3, 1, 64, 64, 0, 64, EPI_NHWC, a, st);
+        // VSRLAB_AMD_GENERIC_CONV=1 (A/B switch): the generic kernel does not write sign bits, but later launches (hr_tail.hip's
+        // conv_last.2 data gradient, the masked data gradients) read them -- r04: the switch gave wrong gradients since round 2
+        if (rc == VSR_OK && sign_out && dtype == VSR_BF16 && vsr_env().generic_conv) return vsr_launch_sign_bits_c64(y, sign_out, N, H, W, st);
+        return rc;
     }
     // conv3x3 64->256 + PixelShuffle(2): x (N,H,W,64) -> y (N,2H,2W,64)   (upsampling.py:10-12)
     int conv_ps(const void* x, size_t wpack, const float* bias4, void* y, int N, int H, int W) const {
