@@ -147,11 +147,9 @@ class FusedAdam(torch.optim.Optimizer):
     def rewind_skipped_step(self):
         """If the last ``step()`` was skipped on the device (non-finite gradient norm), take its count back so that the step
         count matches what ``GradScaler.step`` + ``torch.optim.Adam`` would hold.  Synchronises (reads ``last_grad_norm``)."""
-        skipped = self._step > 0 and not bool(torch.isfinite(self.last_grad_norm).item())
-        if skipped:
+        if self._step > 0 and not bool(torch.isfinite(self.last_grad_norm).item()):
             from .functional import raise_on_chain_timeout
-            raise_on_chain_timeout("FusedAdam skipped a step on a non-finite gradient norm")      # (synchronised already)
-        if skipped:
+            raise_on_chain_timeout("FusedAdam skipped a step on a non-finite gradient norm")      # (synchronised already; raises if that is the cause)
             self._step -= 1
             self._step_t.fill_(float(self._step))
             return True
