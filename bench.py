@@ -373,6 +373,16 @@ def main():
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
     crit = CharbonnierLoss()
     n, t, h, w = args.clips, args.frames, args.height, args.width
+    # Two clips need 231 GiB of the GPU's 268.  A GPU that is not empty (another process, a smaller part) gets the rounds 1-3 workload
+    # instead of an allocation failure in the first warm-up step; the line says so (config.clips_per_gpu, config.clips_note).
+    clips_note = None
+    if n > 1 and world == 1:
+        free_b, _total_b = torch.cuda.mem_get_info(dev)
+        need = n * 116.0 * 2 ** 30 * (h * w * t) / (540.0 * 960 * 7) * (args.res_blocks + 3) / 33.0
+        if args.arena == "full" and args.dtype == "bf16" and free_b < need:
+            clips_note = f"--clips {n} needs ~{need / 2 ** 30:.0f} GiB, {free_b / 2 ** 30:.0f} GiB free: ran 1 clip per GPU"
+            log(clips_note)
+            n = 1
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)             # one distinct clip per rank (weak scaling)
     lrs = torch.rand(n, t, 3, h, w, generator=g).to(dev)
     hr = torch.rand(n, t, 3, 4 * h, 4 * w, generator=g).to(dev)
@@ -420,7 +430,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic (torch.rand clips, random-init weights)",
             "config": {"workload": f"BasicVSR(mid=64,res_blocks={args.res_blocks},x4) fwd+Charbonnier+bwd+clip+Adam, "
                                    f"{h}x{w}->{4 * h}x{4 * w}, {t}-frame clip, {n} clip{'s' if n > 1 else ''} per GPU (BASELINE configs[1]{'/[3]' if world > 1 else ''})",
-                       "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "res_blocks": args.res_blocks,
+                       "clips_per_gpu": n, **({"clips_note": clips_note} if clips_note else {}), "frames": t, "lr_size": [h, w], "res_blocks": args.res_blocks,
                        "parallelism": (f"dp{world} (clip-level; " + ("one RCCL all-reduce of the flat gradient arena per step)" if sync is not None
                                                                         else "DDP grad all-reduce over RCCL)")) if world > 1 else "single GPU",
                        "optimizer_in_timed_region": "fused clip_grad_norm(1)+Adam (HIP)" if args.optimizer == "fused" else "torch.optim.Adam",
